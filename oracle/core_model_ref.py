@@ -1,0 +1,160 @@
+"""Oracle restatement of the reference's model/loss arithmetic (torch CPU fp32).
+
+Test infrastructure (see ``oracle/__init__.py``).  Each function cites the
+reference lines it follows; the code is written from the described behaviour,
+with plain functional torch ops instead of the reference's module plumbing.
+"""
+from __future__ import annotations
+
+from collections.abc import Sequence
+
+import torch
+import torch.nn.functional as F
+
+GRAM_CLAMP_MAX = 5e5  # reference constants.py:15
+
+# A "program" is a list of layer descriptors in torchvision ``features`` order:
+#   ("conv", weight[Cout,Cin,3,3], bias[Cout]) | ("relu",) | ("pool",)
+Layer = tuple
+
+
+def vgg_program(
+    weights: Sequence[tuple[torch.Tensor, torch.Tensor]],
+    cfg: Sequence[int | str],
+) -> list[Layer]:
+    """Expand a VGG cfg into conv/relu/pool descriptors.
+
+    Follows torchvision ``make_layers`` ordering (conv3x3 pad 1, ReLU,
+    MaxPool2d(2,2)); the reference obtains it via ``vgg19().features``
+    (core_model.py:114).
+    """
+    prog: list[Layer] = []
+    it = iter(weights)
+    for v in cfg:
+        if v == "M":
+            prog.append(("pool",))
+        else:
+            w, b = next(it)
+            prog.append(("conv", w, b))
+            prog.append(("relu",))
+    return prog
+
+
+def run_layer(layer: Layer, x: torch.Tensor) -> torch.Tensor:
+    kind = layer[0]
+    if kind == "conv":
+        return F.conv2d(x, layer[1], layer[2], stride=1, padding=1)
+    if kind == "relu":
+        return F.relu(x)  # out-of-place, core_model.py:134-135
+    if kind == "pool":
+        return F.max_pool2d(x, kernel_size=2, stride=2)
+    msg = f"unknown layer kind {kind}"
+    raise ValueError(msg)
+
+
+def gram_matrix(t: torch.Tensor, clamp_max: float = GRAM_CLAMP_MAX) -> torch.Tensor:
+    """core_model.py:29-63: clamp(F F^T, max) / (b*c*h*w), batch folded in."""
+    b, c, h, w = t.shape
+    f = t.reshape(b * c, h * w)
+    g = torch.mm(f, f.t()).clamp(max=clamp_max)
+    return g.div(b * c * h * w)
+
+
+def split_blocks(
+    n_layers: int,
+    style_layers: Sequence[int],
+    content_layers: Sequence[int],
+) -> tuple[list[list[int]], list[int], list[int]]:
+    """core_model.py:120-146: cut after every tapped index, drop the tail.
+
+    Returns (blocks as lists of layer indices, content block ids, style block ids).
+    """
+    blocks: list[list[int]] = []
+    content_ids: list[int] = []
+    style_ids: list[int] = []
+    cur: list[int] = []
+    for i in range(n_layers):
+        cur.append(i)
+        if i in style_layers or i in content_layers:
+            blocks.append(cur)
+            cur = []
+        if i in style_layers:
+            style_ids.append(len(blocks) - 1)
+        if i in content_layers:
+            content_ids.append(len(blocks) - 1)
+    return blocks, content_ids, style_ids
+
+
+class OracleModel:
+    """Functional restatement of ``StyleContentModel`` (core_model.py:149-328)."""
+
+    def __init__(
+        self,
+        program: Sequence[Layer],
+        style_layers: Sequence[int],
+        content_layers: Sequence[int],
+    ) -> None:
+        self.program = list(program)
+        self.blocks, self.content_ids, self.style_ids = split_blocks(
+            len(self.program), list(style_layers), list(content_layers),
+        )
+        self.style_targets: list[torch.Tensor] | None = None
+        self.content_targets: list[torch.Tensor] | None = None
+
+    def _features(self, x: torch.Tensor) -> list[torch.Tensor]:
+        outs = []
+        for blk in self.blocks:
+            for li in blk:
+                x = run_layer(self.program[li], x)
+            outs.append(x)
+        return outs
+
+    def set_targets(self, style_img: torch.Tensor, content_img: torch.Tensor) -> None:
+        """core_model.py:218-232 (two forwards, detached targets)."""
+        with torch.no_grad():
+            sf = self._features(style_img)
+            self.style_targets = [gram_matrix(sf[j]) for j in range(len(sf))
+                                  if j in self.style_ids]
+            cf = self._features(content_img)
+            self.content_targets = [cf[j] for j in range(len(cf))
+                                    if j in self.content_ids]
+
+    def __call__(self, x: torch.Tensor) -> tuple[list[torch.Tensor], list[torch.Tensor]]:
+        """core_model.py:297-328: per-block style MSE(Gram) and content MSE."""
+        if self.style_targets is None:
+            msg = "style_targets must be set before computing losses."
+            raise RuntimeError(msg)
+        if self.content_targets is None:
+            msg = "content_targets must be set before computing losses."
+            raise RuntimeError(msg)
+        style_losses, content_losses = [], []
+        feats = self._features(x)
+        for j, f in enumerate(feats):
+            if j in self.style_ids:
+                tgt = self.style_targets[self.style_ids.index(j)]
+                style_losses.append(F.mse_loss(gram_matrix(f), tgt))
+            if j in self.content_ids:
+                tgt = self.content_targets[self.content_ids.index(j)]
+                content_losses.append(F.mse_loss(f, tgt))
+        return style_losses, content_losses
+
+
+def loss_and_grad(
+    model: OracleModel,
+    x: torch.Tensor,
+    style_w: float,
+    content_w: float,
+) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """optimization.py:286-327: weighted total loss and d(total)/dx.
+
+    Returns (style_score, content_score, total, grad), all detached.
+    """
+    with torch.enable_grad():
+        xr = x.detach().clone().requires_grad_(True)
+        s_losses, c_losses = model(xr)
+        zero = torch.zeros((), dtype=x.dtype)
+        style_score = torch.stack(s_losses).sum() if s_losses else zero
+        content_score = torch.stack(c_losses).sum() if c_losses else zero
+        total = style_w * style_score + content_w * content_score
+        total.backward()
+    return style_score.detach(), content_score.detach(), total.detach(), xr.grad.detach()

@@ -1,0 +1,74 @@
+"""Shared pytest configuration: markers, paths, golden-fixture helpers."""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "slow: longer-running CPU test")
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+class GoldenCase:
+    """One ``tests/golden/<name>.npz`` produced by ``oracle/make_golden.py``."""
+
+    def __init__(self, name: str) -> None:
+        data = np.load(os.path.join(GOLDEN_DIR, f"{name}.npz"))
+        self.arrays = {k: data[k] for k in data.files}
+        self.meta = json.loads(bytes(self.arrays.pop("meta_json")).decode())
+        self.cfg = tuple(v if v == "M" else int(v) for v in self.meta["cfg"])
+
+    def weights(self):
+        from style_transfer_visualizer_amd import synthetic
+        m = self.meta
+        ws = synthetic.synthetic_conv_weights(m["wseed"], self.cfg)
+        out = []
+        for li, (w, b) in enumerate(ws):
+            if li == 0:
+                w = w * m["gain_first"]
+            if m["bias_scale"]:
+                b = synthetic.synthetic_bias(m["wseed"], li, w.shape[0], m["bias_scale"])
+            out.append((w, b))
+        return out
+
+    def images(self):
+        from style_transfer_visualizer_amd import synthetic
+        m = self.meta
+        content = synthetic.synthetic_image(0, *m["hw_content"], normalize=m["normalize"])
+        style = synthetic.synthetic_image(1, *m["hw_style"], normalize=m["normalize"])
+        return content, style
+
+    def tensor(self, key: str) -> torch.Tensor:
+        return torch.from_numpy(np.asarray(self.arrays[key]))
+
+
+GOLDEN_CASES = [
+    "mini_white_lbfgs", "mini_content_lbfgs", "mini_random_lbfgs_nonorm",
+    "mini_white_adam", "mini_clamp_lbfgs", "tiny_taps_lbfgs", "vgg19_white_lbfgs",
+]
+
+
+@pytest.fixture(params=GOLDEN_CASES)
+def golden_case(request) -> GoldenCase:
+    return GoldenCase(request.param)

@@ -1,0 +1,166 @@
+"""Pin the CPU oracle against golden vectors captured from the unmodified reference."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import core_model_ref as ocm
+from oracle import optim_ref
+from tests.conftest import GOLDEN_DIR, GoldenCase
+
+# The oracle uses the same torch CPU kernels in the same order as the reference,
+# so agreement is expected at rounding level; this is the pin tolerance.
+RTOL = 1e-5
+
+
+def _oracle_model(case: GoldenCase) -> ocm.OracleModel:
+    prog = ocm.vgg_program(case.weights(), case.cfg)
+    model = ocm.OracleModel(prog, case.meta["style_layers"], case.meta["content_layers"])
+    content, style = case.images()
+    model.set_targets(style, content)
+    return model
+
+
+def test_gram_known_answers():
+    kats = np.load(os.path.join(GOLDEN_DIR, "gram_kats.npz"))
+    a = torch.from_numpy(kats["kat1_in"])
+    # values observed from the reference's gram_matrix
+    assert ocm.gram_matrix(a).tolist() == [[1.75, 4.75], [4.75, 15.75]]
+    assert ocm.gram_matrix(a, clamp_max=30).tolist() == [[1.75, 3.75], [3.75, 3.75]]
+    assert np.array_equal(ocm.gram_matrix(a).numpy(), kats["kat1_out"])
+    b = torch.from_numpy(kats["kat3_in"])
+    g3 = ocm.gram_matrix(b)
+    assert g3.shape == (4, 4)
+    assert g3[0].tolist() == [0.875, 2.375, 3.875, 5.375]
+    assert np.array_equal(g3.numpy(), kats["kat3_out"])
+    x = a.clone().requires_grad_(True)
+    ocm.gram_matrix(x, clamp_max=30).sum().backward()
+    assert x.grad.flatten().tolist() == [0, .25, .5, .75, 0, 0, 0, 0]
+    f = torch.from_numpy(kats["kat5_in"]).requires_grad_(True)
+    g5 = ocm.gram_matrix(f, clamp_max=20.0)
+    assert np.array_equal(g5.detach().numpy(), kats["kat5_out_clamp20"])
+    loss = torch.nn.functional.mse_loss(g5, torch.from_numpy(kats["kat5_target"]))
+    loss.backward()
+    assert loss.item() == pytest.approx(float(kats["kat5_loss"]), rel=1e-6)
+    np.testing.assert_allclose(f.grad.numpy(), kats["kat5_grad"], rtol=1e-6, atol=1e-7)
+
+
+def test_gram_symmetric_psd():
+    # mirrors /root/reference/tests/test_core_model.py:84-92
+    t = torch.randn(1, 3, 64, 64, generator=torch.Generator().manual_seed(0))
+    g = ocm.gram_matrix(t)
+    assert g.shape == (3, 3)
+    assert torch.allclose(g, g.t())
+    assert torch.all(torch.linalg.eigvals(g).real >= -1e-6)
+
+
+def test_block_split_defaults():
+    # 6 blocks, style ids [0,1,2,3,5], content ids [4]
+    blocks, content_ids, style_ids = ocm.split_blocks(37, [0, 5, 10, 19, 28], [21])
+    assert [b[0] for b in blocks] == [0, 1, 6, 11, 20, 22]
+    assert [b[-1] for b in blocks] == [0, 5, 10, 19, 21, 28]
+    assert style_ids == [0, 1, 2, 3, 5]
+    assert content_ids == [4]
+
+
+def test_oracle_matches_reference_fixture(golden_case: GoldenCase):
+    case = golden_case
+    m = case.meta
+    model = _oracle_model(case)
+    assert len(model.blocks) == m["block_count"]
+    assert model.style_ids == m["style_ids"]
+    assert model.content_ids == m["content_ids"]
+
+    # targets
+    for i, t in enumerate(model.style_targets):
+        if f"style_target_{i}" in case.arrays:
+            np.testing.assert_allclose(t.numpy(), case.arrays[f"style_target_{i}"], rtol=RTOL, atol=1e-7)
+        else:
+            np.testing.assert_allclose(t.numpy()[::16, ::16], case.arrays[f"style_target_{i}_sub16"],
+                                       rtol=RTOL, atol=1e-7)
+            assert float(t.double().sum()) == pytest.approx(float(case.arrays[f"style_target_{i}_sum"]), rel=1e-5)
+    for i, t in enumerate(model.content_targets):
+        assert float(t.double().abs().sum()) == pytest.approx(
+            float(case.arrays[f"content_target_{i}_abs_sum"]), rel=1e-5)
+
+    # step-1 loss triple and gradient at x0
+    x0 = case.tensor("x0")
+    s, c, tot, g = ocm.loss_and_grad(model, x0, m["style_w"], m["content_w"])
+    assert float(s) == pytest.approx(case.arrays["style_loss"][0], rel=RTOL)
+    assert float(c) == pytest.approx(case.arrays["content_loss"][0], rel=RTOL)
+    assert float(tot) == pytest.approx(case.arrays["total_loss"][0], rel=RTOL)
+    g_ref = case.arrays["grad_step1"]
+    np.testing.assert_allclose(g.numpy(), g_ref, rtol=1e-4, atol=1e-6 * np.abs(g_ref).max())
+
+    # full trajectory with the restated optimizer
+    res = optim_ref.run_loop(
+        lambda x: ocm.loss_and_grad(model, x, m["style_w"], m["content_w"]),
+        x0, m["steps"], optimizer=m["optimizer"],
+        lr=m["adam_lr"] if m["optimizer"] == "adam" else None)
+    np.testing.assert_allclose(res["history"]["total"], case.arrays["total_loss"], rtol=1e-4)
+    np.testing.assert_allclose(res["history"]["style"], case.arrays["style_loss"], rtol=1e-4)
+    np.testing.assert_allclose(res["history"]["content"], case.arrays["content_loss"], rtol=1e-4)
+    xf = case.arrays["x_final"]
+    # north_star tolerance: 1e-4 relative per pixel (relative to the image scale)
+    np.testing.assert_allclose(res["x"].numpy(), xf, rtol=1e-4, atol=1e-4 * np.abs(xf).max())
+    assert int(case.arrays["closure_calls"]) == m["steps"]  # 1 closure per step (F5)
+    assert case.arrays["logged_steps"].tolist() == [s for s in range(1, m["steps"] + 1) if s % 2 == 0]
+
+
+def test_lbfgs_restatement_is_torch_lbfgs():
+    """LbfgsRef is bit-identical to torch.optim.LBFGS on CPU (same op order)."""
+    torch.manual_seed(0)
+    a = torch.randn(40, 40)
+    a = a @ a.t() + torch.eye(40)
+    b = torch.randn(40)
+
+    def f(x):
+        return 0.5 * x @ a @ x - b @ x + 0.1 * (x ** 4).sum()
+
+    x_t = torch.zeros(40, requires_grad=True)
+    opt = torch.optim.LBFGS([x_t], lr=0.05, max_iter=1, max_eval=1)
+    x_r = torch.zeros(40)
+    ref = optim_ref.LbfgsRef(x_r, lr=0.05)
+    for _ in range(30):
+        def closure():
+            opt.zero_grad()
+            loss = f(x_t)
+            loss.backward()
+            return loss
+        opt.step(closure)
+
+        def closure_r():
+            with torch.enable_grad():
+                xr = x_r.detach().clone().requires_grad_(True)
+                loss = f(xr)
+                loss.backward()
+            return loss.detach(), xr.grad
+        ref.step(closure_r)
+        assert torch.equal(x_t.detach(), x_r)
+
+
+def test_adam_restatement_is_torch_adam():
+    torch.manual_seed(1)
+    x_t = torch.randn(64, requires_grad=True)
+    x_r = x_t.detach().clone()
+    opt = torch.optim.Adam([x_t], lr=1e-2)
+    ref = optim_ref.AdamRef(x_r, lr=1e-2)
+    for _ in range(10):
+        def closure():
+            opt.zero_grad()
+            loss = (x_t ** 2).sum() + x_t.sin().sum()
+            loss.backward()
+            return loss
+        opt.step(closure)
+
+        def closure_r():
+            with torch.enable_grad():
+                xr = x_r.detach().clone().requires_grad_(True)
+                loss = (xr ** 2).sum() + xr.sin().sum()
+                loss.backward()
+            return loss.detach(), xr.grad
+        ref.step(closure_r)
+    torch.testing.assert_close(x_t.detach(), x_r, rtol=1e-6, atol=1e-7)
