@@ -1,0 +1,169 @@
+/*
+ * stv.h - C ABI of libstv_hip.so: the MI355X (gfx950) kernels behind the
+ * per-step optimisation path of style_transfer_visualizer.
+ *
+ * The reference has no FFI; its boundary for this path is the Python API of
+ * core_model.py / optimization.py, whose arithmetic is delegated to torch.
+ * Each entry point below replaces the torch op(s) issued at the cited
+ * reference line (paths relative to
+ * /root/reference/src/style_transfer_visualizer/).  See INTEGRATION.md for the
+ * ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller (PyTorch allocates);
+ *    the library never frees or retains a pointer past the call, except the
+ *    command buffer of stv_exec_*, which is copied at creation;
+ *  - activations are NHWC ([H][W][C], batch 1) in `dtype` storage
+ *    (STV_F32 | STV_BF16); the image and its gradient are NCHW fp32, exactly
+ *    the tensors the reference optimises (core_model.py:66-100);
+ *  - `stream` is a hipStream_t; all work is enqueued on it, nothing syncs;
+ *  - return value: 0 = ok, otherwise an STV_ERR_* code (Python raises
+ *    RuntimeError).  No CPU fallback exists.
+ */
+#ifndef STV_H_
+#define STV_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { STV_F32 = 0, STV_BF16 = 1 };
+
+enum {
+  STV_OK = 0,
+  STV_ERR_ARG = 1,      /* unsupported shape / null pointer / bad dtype */
+  STV_ERR_LAUNCH = 2,   /* hipGetLastError() after a launch */
+  STV_ERR_ALLOC = 3,
+  STV_ERR_GRAPH = 4
+};
+
+/* flags */
+enum {
+  STV_RELU_IN = 1,   /* apply max(0,.) to the input while staging it */
+  STV_RELU_OUT = 2,  /* apply max(0,.) before storing (conv+ReLU fusion) */
+  STV_MASK = 4,      /* multiply result by (ref > 0): ReLU backward */
+  STV_ACCUM = 8,     /* out += result instead of out = result */
+  STV_NO_BIAS = 16
+};
+
+int stv_version(void);
+/* Algorithmic workspace sizing helpers (bytes). */
+size_t stv_gram_partials_bytes(int n_pixels, int channels);
+int stv_gram_ksplit(int n_pixels, int channels);
+
+/* ---- VGG conv3x3 stacks: replaces F.conv2d / relu / max_pool2d issued by
+ *      `x = block(x)` (core_model.py:316) and their autograd backward
+ *      (`loss.backward()`, optimization.py:313). ---------------------------- */
+
+/* First conv: NCHW fp32 image [cin][H][W] -> NHWC `dtype` [H][W][cout].
+ * wf is [9][cout][cin] fp32 (tap = ky*3+kx), bias fp32[cout]. */
+int stv_conv_first_fwd(const float* x_nchw, const float* wf, const float* bias,
+                       void* y, int H, int W, int cin, int cout, int dtype,
+                       void* stream);
+/* Its input-gradient: dy NHWC `dtype` [H][W][cout] -> dx NCHW fp32 [cin][H][W].
+ * wf is the same forward-packed fp32 weight. */
+int stv_conv_first_dgrad(const void* dy, const float* wf, float* dx_nchw,
+                         int H, int W, int cin, int cout, int dtype, void* stream);
+
+/* Implicit-GEMM 3x3 conv, pad 1, stride 1, NHWC.  `w` is [taps][cout][cin] in
+ * `dtype` (K-contiguous rows); bias fp32[cout] or NULL.  taps = 9 (3x3) or 1
+ * (1x1, used for the Gram backward product).  flags: RELU_IN, RELU_OUT,
+ * MASK (needs `ref`, NHWC [H][W][cout]), ACCUM.  The same entry computes the
+ * input gradient when given the flipped/transposed weights (dgrad). */
+int stv_conv_igemm(const void* x, const void* w, const float* bias, const void* ref,
+                   void* y, int H, int W, int cin, int cout, int taps, int flags,
+                   int dtype, void* stream);
+
+/* MaxPool2d(2,2) forward / backward (first-max-wins like torch); backward
+ * optionally applies the ReLU mask of the stored pre-pool activation. */
+int stv_maxpool_fwd(const void* x, void* y, int H, int W, int C, int dtype, void* stream);
+int stv_maxpool_bwd(const void* x, const void* dy, void* dx, int H, int W, int C,
+                    int flags, int dtype, void* stream);
+int stv_relu_fwd(const void* x, void* y, size_t n, int dtype, void* stream);
+/* dx (=|+=) (x > 0) * dy ; dx may alias dy */
+int stv_relu_bwd(const void* x, const void* dy, void* dx, size_t n, int flags,
+                 int dtype, void* stream);
+
+/* ---- Gram / style loss: replaces gram_matrix (core_model.py:29-63:
+ *      mm(F,F^T).clamp(max).div(b*c*h*w)) + mse_loss (core_model.py:264) and
+ *      their backward. ----------------------------------------------------- */
+
+/* Split-K partial sums of F^T F over pixels.  F is NHWC [n_pixels][C];
+ * partials is fp32 [ksplit][C][C] (upper tile triangle valid). */
+int stv_gram_partial(const void* F, float* partials, int n_pixels, int C,
+                     int dtype, void* stream);
+/* Reduce partials -> raw Gram R; G = min(R, clamp_max) / norm.
+ *  gram_out  (optional) fp32 [C][C]  <- G            (target capture)
+ *  target    (optional) fp32 [C][C]
+ *  loss_part (optional) fp32 [stv_gram_loss_parts(C)] <- partial sums of (G-T)^2
+ *  sgrad     (optional) `dtype` [C][C] <- coef*(*coef_dev)*4/(C*C*norm) * (R<=clamp) * (G-T)
+ */
+int stv_gram_loss_parts(int channels);
+int stv_gram_finish(const float* partials, const float* target, float* gram_out,
+                    float* loss_part, void* sgrad, int n_pixels, int C, float clamp_max,
+                    float norm, float coef, const float* coef_dev, int dtype, void* stream);
+
+/* ---- Content loss: mse_loss(features, target) (core_model.py:295). -------- */
+#define STV_CONTENT_LOSS_PARTS 256
+int stv_content_loss(const void* F, const void* target, float* loss_part, size_t n,
+                     int dtype, void* stream);
+/* dF (=|+=) coef*(*coef_dev)*(2/n)*(F - target) */
+int stv_content_grad(const void* F, const void* target, void* dF, size_t n, float coef,
+                     const float* coef_dev, int flags, int dtype, void* stream);
+
+/* ---- Score combine: torch.stack(losses).sum() and
+ *      loss = style_w*style + content_w*content (optimization.py:298-312).
+ *  table: int32 [n_terms][3] = {offset into parts, count, kind(0 style,1 content)}
+ *  scale: fp32 [n_terms] (1/C^2 for style, 1/n for content)
+ *  losses: fp32 [n_terms]; scores: fp32 [4] = {style, content, total, finite_flag} */
+int stv_loss_combine(const float* parts, const int32_t* table, const float* scale,
+                     int n_terms, float style_w, float content_w, float* losses,
+                     float* scores, void* stream);
+
+/* ---- Optimizer updates (torch.optim.LBFGS.step / Adam.step driven from
+ *      optimization.py:175), device resident: no host synchronisation. ----- */
+
+typedef struct stv_lbfgs_state stv_lbfgs_state;  /* opaque, lives in device memory */
+size_t stv_lbfgs_state_bytes(int history);
+size_t stv_lbfgs_workspace_bytes(size_t n, int history);
+/* state/workspace zero-initialised by the caller before the first step. */
+int stv_lbfgs_step(float* x, const float* grad, void* state, void* workspace, size_t n,
+                   int history, int m_max, float lr, float tol_grad, float tol_change,
+                   void* stream);
+/* scalars are computed in double on the host exactly as torch does
+ * (1-beta1, 1-beta2, 1-beta1**t, sqrt(1-beta2**t)) and passed rounded to fp32 */
+int stv_adam_step(float* x, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
+                  float lr, float one_minus_beta1, float beta2, float one_minus_beta2, float eps,
+                  float bias_c1, float bias_c2_sqrt, void* stream);
+
+/* ---- Command-buffer executor: one call runs a whole forward(+backward)
+ *      schedule built by the host (style_transfer_visualizer_amd/plan.py);
+ *      optionally captured into a hipGraph and replayed. ------------------- */
+enum {
+  STV_OP_CONV_FIRST_FWD = 1, STV_OP_CONV_FIRST_DGRAD, STV_OP_CONV, STV_OP_POOL_FWD,
+  STV_OP_POOL_BWD, STV_OP_RELU_FWD, STV_OP_RELU_BWD, STV_OP_GRAM_PARTIAL,
+  STV_OP_GRAM_FINISH, STV_OP_CONTENT_LOSS, STV_OP_CONTENT_GRAD, STV_OP_LOSS_COMBINE,
+  STV_OP_MEMSET
+};
+typedef struct {
+  int32_t op, dtype, flags, taps;
+  int32_t H, W, cin, cout;
+  int64_t n;
+  float f0, f1, f2, f3;
+  const void* p0; const void* p1; const void* p2; const void* p3;
+  void* q0; void* q1; void* q2; void* q3;
+} stv_op_t;
+
+typedef struct stv_program stv_program;  /* host object */
+int stv_program_create(const stv_op_t* ops, int n_ops, stv_program** out);
+/* use_graph != 0: capture on first run, replay afterwards. */
+int stv_program_run(stv_program* prog, int use_graph, void* stream);
+void stv_program_destroy(stv_program* prog);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STV_H_ */

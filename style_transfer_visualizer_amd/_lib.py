@@ -1,0 +1,92 @@
+"""ctypes binding of ``libstv_hip.so`` (C ABI declared in ``include/stv.h``).
+
+The library is the product: there is no eager/PyTorch or CPU fallback.  If it
+is missing or a call fails, a ``RuntimeError`` is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libstv_hip.so")
+
+STV_F32, STV_BF16 = 0, 1
+RELU_IN, RELU_OUT, MASK, ACCUM = 1, 2, 4, 8
+
+(OP_CONV_FIRST_FWD, OP_CONV_FIRST_DGRAD, OP_CONV, OP_POOL_FWD, OP_POOL_BWD, OP_RELU_FWD,
+ OP_RELU_BWD, OP_GRAM_PARTIAL, OP_GRAM_FINISH, OP_CONTENT_LOSS, OP_CONTENT_GRAD,
+ OP_LOSS_COMBINE, OP_MEMSET) = range(1, 14)
+
+CONTENT_LOSS_PARTS = 256
+
+_ERRORS = {1: "STV_ERR_ARG (unsupported shape / null pointer / dtype)",
+           2: "STV_ERR_LAUNCH (HIP launch failed)", 3: "STV_ERR_ALLOC", 4: "STV_ERR_GRAPH"}
+
+
+class StvOp(ctypes.Structure):
+    """Mirror of ``stv_op_t`` (include/stv.h)."""
+
+    _fields_ = [
+        ("op", c_int32), ("dtype", c_int32), ("flags", c_int32), ("taps", c_int32),
+        ("H", c_int32), ("W", c_int32), ("cin", c_int32), ("cout", c_int32),
+        ("n", c_int64),
+        ("f0", c_float), ("f1", c_float), ("f2", c_float), ("f3", c_float),
+        ("p0", c_void_p), ("p1", c_void_p), ("p2", c_void_p), ("p3", c_void_p),
+        ("q0", c_void_p), ("q1", c_void_p), ("q2", c_void_p), ("q3", c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/stv.h declares
+SIGNATURES = {
+    "stv_version": (c_int, []),
+    "stv_gram_partials_bytes": (c_size_t, [c_int, c_int]),
+    "stv_gram_ksplit": (c_int, [c_int, c_int]),
+    "stv_gram_loss_parts": (c_int, [c_int]),
+    "stv_conv_first_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "stv_conv_first_dgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "stv_conv_igemm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "stv_maxpool_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "stv_maxpool_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "stv_relu_fwd": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "stv_relu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
+    "stv_gram_partial": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "stv_gram_finish": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_void_p, c_int, c_void_p]),
+    "stv_content_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "stv_content_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_void_p, c_int, c_int, c_void_p]),
+    "stv_loss_combine": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    "stv_lbfgs_state_bytes": (c_size_t, [c_int]),
+    "stv_lbfgs_workspace_bytes": (c_size_t, [c_size_t, c_int]),
+    "stv_lbfgs_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_float, c_float, c_float, c_void_p]),
+    "stv_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float, c_float, c_float, c_float, c_float, c_void_p]),
+    "stv_program_create": (c_int, [ctypes.POINTER(StvOp), c_int, ctypes.POINTER(c_void_p)]),
+    "stv_program_run": (c_int, [c_void_p, c_int, c_void_p]),
+    "stv_program_destroy": (None, [c_void_p]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the HIP library or fail loudly (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        msg = (f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+               "(hipcc --offload-arch=gfx950). There is no CPU/eager fallback for this path.")
+        raise RuntimeError(msg)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = f"{what} failed: {_ERRORS.get(rc, rc)}"
+        raise RuntimeError(msg)

@@ -1,0 +1,350 @@
+// Implicit-GEMM 3x3 (and 1x1) convolution on the CDNA4 matrix cores, NHWC.
+//
+//   y[p][n] = sum_{tap} sum_{c} x[p + off(tap)][c] * w[tap][n][c]   (+bias, epilogue)
+//
+// M = pixels, N = output channels, K = taps * Cin.  A workgroup owns a
+// TH x 32 pixel tile and BN output channels.  Per K-stage (32 bytes of K per
+// pixel: 16 bf16 / 8 fp32 channels) it stages the (TH+2) x 34 halo tile of the
+// input and the [taps][BN] weight rows for that channel slice in LDS, then
+// every wave walks the 9 taps as shifted windows of the same LDS tile, so the
+// input is fetched ~1.3x (halo) instead of 9x.  Global loads for stage s+1 are
+// issued before the MFMAs of stage s and written to the other LDS buffer after
+// them (issue-early / write-late), one barrier per stage.
+//
+// MFMA shapes: bf16 -> v_mfma_f32_32x32x16_bf16 (lane (r,h) holds k = 8h..8h+7),
+//              fp32 -> v_mfma_f32_32x32x2_f32 x4 with lane (r,h) holding
+//              k = 4h..4h+3 (any k permutation is fine as long as A and B agree).
+// A 32-pixel MFMA row block is one 32-wide image row segment, so the 16-lane
+// groups of ds_read_b128 hit 16 distinct 16-byte slots (row pitch 48 B).
+//
+// The same kernel computes the input gradient (dgrad) when handed the flipped,
+// transposed weights, and the Gram backward product dF = F * S as a 1x1 conv.
+#include "stv_common.h"
+
+namespace {
+
+template <typename T, int TH_, int BN_, int WM_, int WN_, int TAPS_>
+struct Cfg {
+  using Elem = T;
+  static constexpr int TH = TH_, BN = BN_, WM = WM_, WN = WN_, TAPS = TAPS_;
+  static constexpr int TW = 32;
+  static constexpr int KB = 32;                      // K bytes per pixel per stage
+  static constexpr int CK = KB / (int)sizeof(T);     // channels per stage
+  static constexpr int ROWB = KB + 16;               // padded LDS row pitch
+  static constexpr int HALO = (TAPS == 9) ? 1 : 0;
+  static constexpr int IN_H = TH + 2 * HALO, IN_W = TW + 2 * HALO;
+  static constexpr int IN_PIX = IN_H * IN_W;
+  static constexpr int IN_BYTES = IN_PIX * ROWB;
+  static constexpr int W_ROWS = TAPS * BN;
+  static constexpr int W_BYTES = W_ROWS * ROWB;
+  static constexpr int STAGE_BYTES = IN_BYTES + W_BYTES;
+  static constexpr int MT = TH / WM;
+  static constexpr int NT = BN / WN / 32;
+  static constexpr int THREADS = 256;
+  static constexpr int IN_VECS = IN_PIX * 2;
+  static constexpr int W_VECS = W_ROWS * 2;
+  static constexpr int IN_ITERS = (IN_VECS + THREADS - 1) / THREADS;
+  static constexpr int W_ITERS = (W_VECS + THREADS - 1) / THREADS;
+  static constexpr int BM = TH * TW;
+  static constexpr int CS = BN + 4;                  // C-tile pitch in floats
+  static constexpr int C_BYTES = BM * CS * 4;
+  static constexpr int LDS_BYTES = (2 * STAGE_BYTES > C_BYTES) ? 2 * STAGE_BYTES : C_BYTES;
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  static_assert(TH % WM == 0 && BN % (WN * 32) == 0, "tile split");
+  static_assert(STAGE_BYTES % 16 == 0, "16-byte aligned stages");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+struct ConvArgs {
+  const void* x;
+  const void* w;
+  const float* bias;
+  const void* ref;
+  void* y;
+  int H, W, cin, cout, flags;
+};
+
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> { using type = bf16x8v; };
+template <> struct Frag<float> { using type = f32x4; };
+
+template <typename T>
+__device__ __forceinline__ void mma(const typename Frag<T>::type& a,
+                                    const typename Frag<T>::type& b, f32x16& acc);
+template <>
+__device__ __forceinline__ void mma<bf16_t>(const bf16x8v& a, const bf16x8v& b, f32x16& acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma<float>(const f32x4& a, const f32x4& b, f32x16& acc) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
+}
+
+template <typename C>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+  using T = typename C::Elem;
+  using FragT = typename Frag<T>::type;
+  constexpr int kVec = elem_traits<T>::kVec;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / C::WN, wn = wave % C::WN;
+  const int r = lane & 31, h = lane >> 5;
+
+  const int tiles_x = (a.W + C::TW - 1) / C::TW;
+  const int tile_x = blockIdx.x % tiles_x;
+  const int tile_y = blockIdx.x / tiles_x;
+  const int x0 = tile_x * C::TW, y0 = tile_y * C::TH;
+  const int n0 = blockIdx.y * C::BN;
+
+  const T* __restrict__ xin = static_cast<const T*>(a.x);
+  const T* __restrict__ wgt = static_cast<const T*>(a.w);
+  const bool relu_in = (a.flags & STV_RELU_IN) != 0;
+
+  // ---- per-thread staging descriptors (element offsets, -1 = zero fill) ----
+  int in_off[C::IN_ITERS];
+  int in_lds[C::IN_ITERS];
+#pragma unroll
+  for (int it = 0; it < C::IN_ITERS; ++it) {
+    const int v = it * C::THREADS + tid;
+    const int pix = v >> 1, half = v & 1;
+    const int py = pix / C::IN_W, px = pix - py * C::IN_W;
+    const int gy = y0 + py - C::HALO, gx = x0 + px - C::HALO;
+    const bool ok = (v < C::IN_VECS) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+    in_off[it] = ok ? ((gy * a.W + gx) * a.cin + half * kVec) : -1;
+    in_lds[it] = (v < C::IN_VECS) ? (pix * C::ROWB + half * 16) : -1;
+  }
+  int w_off[C::W_ITERS];
+  int w_lds[C::W_ITERS];
+#pragma unroll
+  for (int it = 0; it < C::W_ITERS; ++it) {
+    const int v = it * C::THREADS + tid;
+    const int row = v >> 1, half = v & 1;
+    const int tap = row / C::BN, n = row - tap * C::BN;
+    const bool ok = (v < C::W_VECS) && (n0 + n) < a.cout;
+    w_off[it] = ok ? ((tap * a.cout + n0 + n) * a.cin + half * kVec) : -1;
+    w_lds[it] = (v < C::W_VECS) ? (C::IN_BYTES + row * C::ROWB + half * 16) : -1;
+  }
+
+  u32x4 in_reg[C::IN_ITERS];
+  u32x4 w_reg[C::W_ITERS];
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+  auto stage_load = [&](int c0) {
+#pragma unroll
+    for (int it = 0; it < C::IN_ITERS; ++it)
+      in_reg[it] = (in_off[it] >= 0)
+                       ? *reinterpret_cast<const u32x4*>(xin + in_off[it] + c0)
+                       : zero4;
+#pragma unroll
+    for (int it = 0; it < C::W_ITERS; ++it)
+      w_reg[it] = (w_off[it] >= 0)
+                      ? *reinterpret_cast<const u32x4*>(wgt + w_off[it] + c0)
+                      : zero4;
+  };
+  auto stage_write = [&](char* buf) {
+#pragma unroll
+    for (int it = 0; it < C::IN_ITERS; ++it)
+      if (in_lds[it] >= 0)
+        *reinterpret_cast<u32x4*>(buf + in_lds[it]) = relu_in ? relu16<T>(in_reg[it]) : in_reg[it];
+#pragma unroll
+    for (int it = 0; it < C::W_ITERS; ++it)
+      if (w_lds[it] >= 0) *reinterpret_cast<u32x4*>(buf + w_lds[it]) = w_reg[it];
+  };
+
+  f32x16 acc[C::MT][C::NT];
+#pragma unroll
+  for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.0f;
+
+  // lane-constant LDS byte offsets of this lane's A / B fragment rows
+  const int a_lane = ((wm * C::MT) * C::IN_W + r) * C::ROWB + h * 16;
+  const int b_lane = C::IN_BYTES + (wn * (C::NT * 32) + r) * C::ROWB + h * 16;
+
+  const int nchunks = a.cin / C::CK;
+  stage_load(0);
+  stage_write(smem);
+  __syncthreads();
+
+  for (int c = 0; c < nchunks; ++c) {
+    char* cur = smem + (c & 1) * C::STAGE_BYTES;
+    char* nxt = smem + ((c + 1) & 1) * C::STAGE_BYTES;
+    const bool more = (c + 1) < nchunks;
+    if (more) stage_load((c + 1) * C::CK);
+
+#pragma unroll
+    for (int tap = 0; tap < C::TAPS; ++tap) {
+      const int dy = (C::TAPS == 9) ? tap / 3 : 0;
+      const int dx = (C::TAPS == 9) ? tap % 3 : 0;
+      FragT bf[C::NT];
+      FragT af[C::MT];
+#pragma unroll
+      for (int nt = 0; nt < C::NT; ++nt)
+        bf[nt] = *reinterpret_cast<const FragT*>(cur + b_lane + (tap * C::BN + nt * 32) * C::ROWB);
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt)
+        af[mt] = *reinterpret_cast<const FragT*>(cur + a_lane + ((mt + dy) * C::IN_W + dx) * C::ROWB);
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < C::NT; ++nt) mma<T>(af[mt], bf[nt], acc[mt][nt]);
+    }
+
+    if (more) stage_write(nxt);
+    __syncthreads();
+  }
+
+  // ---- epilogue: accumulators -> LDS C tile (fp32) -> 16-byte vector stores ----
+  float* cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = (wm * C::MT + mt) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        const int col = wn * (C::NT * 32) + nt * 32 + r;
+        cs[row * C::CS + col] = acc[mt][nt][i];
+      }
+  __syncthreads();
+
+  T* __restrict__ yout = static_cast<T*>(a.y);
+  const T* __restrict__ ref = static_cast<const T*>(a.ref);
+  const bool relu_out = (a.flags & STV_RELU_OUT) != 0;
+  const bool do_mask = (a.flags & STV_MASK) != 0;
+  const bool do_acc = (a.flags & STV_ACCUM) != 0;
+  const bool has_bias = a.bias != nullptr;
+  constexpr int VPR = C::BN / kVec;  // vectors per pixel row of the tile
+  constexpr int TOTAL = C::BM * VPR;
+  for (int v = tid; v < TOTAL; v += C::THREADS) {
+    const int pix = v / VPR, cv = v - pix * VPR;
+    const int gy = y0 + (pix >> 5), gx = x0 + (pix & 31);
+    const int n = n0 + cv * kVec;
+    if (gy >= a.H || gx >= a.W || n >= a.cout) continue;
+    float val[kVec];
+#pragma unroll
+    for (int q = 0; q < kVec / 4; ++q) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(cs + pix * C::CS + cv * kVec + q * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) val[q * 4 + e] = t[e];
+    }
+    if (has_bias) {
+#pragma unroll
+      for (int e = 0; e < kVec; ++e) val[e] += a.bias[n + e];
+    }
+    if (relu_out) {
+#pragma unroll
+      for (int e = 0; e < kVec; ++e) val[e] = fmaxf(val[e], 0.0f);
+    }
+    const size_t o = ((size_t)gy * a.W + gx) * a.cout + n;
+    if (do_mask) {
+      float m[kVec];
+      unpack16<T>(*reinterpret_cast<const u32x4*>(ref + o), m);
+#pragma unroll
+      for (int e = 0; e < kVec; ++e) val[e] = (m[e] > 0.0f) ? val[e] : 0.0f;
+    }
+    if (do_acc) {
+      float old[kVec];
+      unpack16<T>(*reinterpret_cast<const u32x4*>(yout + o), old);
+#pragma unroll
+      for (int e = 0; e < kVec; ++e) val[e] += old[e];
+    }
+    *reinterpret_cast<u32x4*>(yout + o) = pack16<T>(val);
+  }
+}
+
+// ---- generic direct fallback (any Cin/Cout; used for odd shapes in tests) ----
+template <typename T, int TAPS>
+__global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs a) {
+  const size_t total = (size_t)a.H * a.W * a.cout;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int n = (int)(idx % a.cout);
+  const size_t p = idx / a.cout;
+  const int gx = (int)(p % a.W), gy = (int)(p / a.W);
+  const T* __restrict__ xin = static_cast<const T*>(a.x);
+  const T* __restrict__ wgt = static_cast<const T*>(a.w);
+  const bool relu_in = (a.flags & STV_RELU_IN) != 0;
+  float s = 0.0f;
+  for (int tap = 0; tap < TAPS; ++tap) {
+    const int yy = gy + ((TAPS == 9) ? tap / 3 - 1 : 0);
+    const int xx = gx + ((TAPS == 9) ? tap % 3 - 1 : 0);
+    if (yy < 0 || yy >= a.H || xx < 0 || xx >= a.W) continue;
+    const T* xp = xin + ((size_t)yy * a.W + xx) * a.cin;
+    const T* wp = wgt + ((size_t)tap * a.cout + n) * a.cin;
+    for (int c = 0; c < a.cin; ++c) {
+      float xv = elem_traits<T>::load(xp + c);
+      if (relu_in) xv = fmaxf(xv, 0.0f);
+      s = fmaf(xv, elem_traits<T>::load(wp + c), s);
+    }
+  }
+  if (a.bias) s += a.bias[n];
+  if (a.flags & STV_RELU_OUT) s = fmaxf(s, 0.0f);
+  T* yout = static_cast<T*>(a.y);
+  if (a.flags & STV_MASK) {
+    const float m = elem_traits<T>::load(static_cast<const T*>(a.ref) + idx);
+    s = (m > 0.0f) ? s : 0.0f;
+  }
+  if (a.flags & STV_ACCUM) s += elem_traits<T>::load(yout + idx);
+  elem_traits<T>::store(yout + idx, s);
+}
+
+template <typename C>
+int launch_cfg(const ConvArgs& a, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<C>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
+      return STV_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int tiles = ceil_div(a.W, C::TW) * ceil_div(a.H, C::TH);
+  dim3 grid(tiles, ceil_div(a.cout, C::BN));
+  hipLaunchKernelGGL(conv_igemm_kernel<C>, grid, dim3(256), C::LDS_BYTES, st, a);
+  STV_CHECK_LAUNCH();
+  return STV_OK;
+}
+
+template <typename T, int TAPS>
+int launch_typed(const ConvArgs& a, hipStream_t st) {
+  constexpr int kVec = elem_traits<T>::kVec;
+  constexpr int CK = 32 / (int)sizeof(T);
+  const bool mfma_ok = (a.cin % CK == 0) && (a.cout % kVec == 0);
+  if (!mfma_ok) {
+    const size_t total = (size_t)a.H * a.W * a.cout;
+    hipLaunchKernelGGL((conv_direct_kernel<T, TAPS>), dim3((unsigned)((total + 255) / 256)),
+                       dim3(256), 0, st, a);
+    STV_CHECK_LAUNCH();
+    return STV_OK;
+  }
+  if (a.cout <= 64) {
+    if (a.H <= 4) return launch_cfg<Cfg<T, 4, 64, 4, 1, TAPS>>(a, st);
+    return launch_cfg<Cfg<T, 8, 64, 4, 1, TAPS>>(a, st);
+  }
+  if (a.H <= 4) return launch_cfg<Cfg<T, 4, 128, 1, 4, TAPS>>(a, st);
+  return launch_cfg<Cfg<T, 8, 128, 2, 2, TAPS>>(a, st);
+}
+
+}  // namespace
+
+extern "C" int stv_conv_igemm(const void* x, const void* w, const float* bias, const void* ref,
+                              void* y, int H, int W, int cin, int cout, int taps, int flags,
+                              int dtype, void* stream) {
+  if (!x || !w || !y || H <= 0 || W <= 0 || cin <= 0 || cout <= 0) return STV_ERR_ARG;
+  if ((flags & STV_MASK) && !ref) return STV_ERR_ARG;
+  if (taps != 9 && taps != 1) return STV_ERR_ARG;
+  if ((size_t)H * W * (size_t)(cin > cout ? cin : cout) >= (size_t)1 << 31) return STV_ERR_ARG;
+  ConvArgs a{x, w, bias, ref, y, H, W, cin, cout, flags};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == STV_F32)
+    return taps == 9 ? launch_typed<float, 9>(a, st) : launch_typed<float, 1>(a, st);
+  if (dtype == STV_BF16)
+    return taps == 9 ? launch_typed<bf16_t, 9>(a, st) : launch_typed<bf16_t, 1>(a, st);
+  return STV_ERR_ARG;
+}

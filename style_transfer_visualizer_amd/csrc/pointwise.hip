@@ -1,0 +1,344 @@
+// HBM-bound pointwise / small-reduction kernels around the conv stacks:
+// MaxPool2d(2,2) forward/backward, ReLU forward/backward, content MSE and its
+// gradient, and the final score combine.  All activation traffic is 16-byte
+// vectors per lane (1 KiB per wave instruction); grids are capped and
+// grid-strided.
+#include "stv_common.h"
+
+namespace {
+
+constexpr int kMaxBlocks = 256 * 8;
+
+inline unsigned grid_for(size_t work_items) {
+  size_t b = (work_items + 255) / 256;
+  if (b < 1) b = 1;
+  if (b > (size_t)kMaxBlocks) b = kMaxBlocks;
+  return (unsigned)b;
+}
+
+// ---------------------------------------------------------------- max pool
+// x: [H][W][C] -> y: [H/2][W/2][C] (floor), vectors of kVec channels.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                          int H, int W, int C) {
+  constexpr int kVec = elem_traits<T>::kVec;
+  const int Ho = H / 2, Wo = W / 2, CV = C / kVec;
+  const size_t total = (size_t)Ho * Wo * CV;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int cv = (int)(i % CV);
+    const size_t p = i / CV;
+    const int ox = (int)(p % Wo), oy = (int)(p / Wo);
+    const T* b = x + ((size_t)(2 * oy) * W + 2 * ox) * C + cv * kVec;
+    float v00[kVec], v01[kVec], v10[kVec], v11[kVec], o[kVec];
+    unpack16<T>(*reinterpret_cast<const u32x4*>(b), v00);
+    unpack16<T>(*reinterpret_cast<const u32x4*>(b + C), v01);
+    unpack16<T>(*reinterpret_cast<const u32x4*>(b + (size_t)W * C), v10);
+    unpack16<T>(*reinterpret_cast<const u32x4*>(b + (size_t)W * C + C), v11);
+#pragma unroll
+    for (int e = 0; e < kVec; ++e) o[e] = fmaxf(fmaxf(v00[e], v01[e]), fmaxf(v10[e], v11[e]));
+    *reinterpret_cast<u32x4*>(y + p * C + cv * kVec) = pack16<T>(o);
+  }
+}
+
+// dx[window] = dy routed to the first maximum in scan order (torch semantics),
+// optionally masked by (x > 0) for a fused ReLU backward; rows/cols dropped by
+// the floor get zero.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x,
+                                                          const T* __restrict__ dy, T* __restrict__ dx,
+                                                          int H, int W, int C, int flags) {
+  constexpr int kVec = elem_traits<T>::kVec;
+  const int Ho = H / 2, Wo = W / 2, CV = C / kVec;
+  const int Hc = (H + 1) / 2, Wc = (W + 1) / 2;  // cover odd tails
+  const bool mask = (flags & STV_MASK) != 0;
+  const bool accum = (flags & STV_ACCUM) != 0;
+  const size_t total = (size_t)Hc * Wc * CV;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int cv = (int)(i % CV);
+    const size_t p = i / CV;
+    const int ox = (int)(p % Wc), oy = (int)(p / Wc);
+    const int iy = 2 * oy, ix = 2 * ox;
+    const bool inside = oy < Ho && ox < Wo;
+    float g[kVec], v[4][kVec], out[4][kVec];
+#pragma unroll
+    for (int e = 0; e < kVec; ++e) g[e] = 0.0f;
+    if (inside) unpack16<T>(*reinterpret_cast<const u32x4*>(dy + ((size_t)oy * Wo + ox) * C + cv * kVec), g);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int yy = iy + (q >> 1), xx = ix + (q & 1);
+      if (yy < H && xx < W)
+        unpack16<T>(*reinterpret_cast<const u32x4*>(x + ((size_t)yy * W + xx) * C + cv * kVec), v[q]);
+      else
+#pragma unroll
+        for (int e = 0; e < kVec; ++e) v[q][e] = 0.0f;
+    }
+#pragma unroll
+    for (int e = 0; e < kVec; ++e) {
+      int best = 0;
+      float bv = v[0][e];
+      // strict '>' keeps the first maximum; NaN wins like torch's (val > max || isnan(val))
+#pragma unroll
+      for (int q = 1; q < 4; ++q)
+        if (v[q][e] > bv || (v[q][e] != v[q][e] && bv == bv)) { bv = v[q][e]; best = q; }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float gq = (inside && q == best) ? g[e] : 0.0f;
+        if (mask && !(v[q][e] > 0.0f)) gq = 0.0f;
+        out[q][e] = gq;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int yy = iy + (q >> 1), xx = ix + (q & 1);
+      if (yy < H && xx < W) {
+        T* o = dx + ((size_t)yy * W + xx) * C + cv * kVec;
+        if (accum) {
+          float old[kVec];
+          unpack16<T>(*reinterpret_cast<const u32x4*>(o), old);
+#pragma unroll
+          for (int e = 0; e < kVec; ++e) out[q][e] += old[e];
+        }
+        *reinterpret_cast<u32x4*>(o) = pack16<T>(out[q]);
+      }
+    }
+  }
+}
+
+// scalar variants for channel counts that are not a multiple of the vector width
+template <typename T>
+__global__ void maxpool_fwd_scalar(const T* __restrict__ x, T* __restrict__ y, int H, int W, int C) {
+  const int Ho = H / 2, Wo = W / 2;
+  const size_t total = (size_t)Ho * Wo * C;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const size_t p = i / C;
+    const int ox = (int)(p % Wo), oy = (int)(p / Wo);
+    const T* b = x + ((size_t)(2 * oy) * W + 2 * ox) * C + c;
+    const float m = fmaxf(fmaxf(elem_traits<T>::load(b), elem_traits<T>::load(b + C)),
+                          fmaxf(elem_traits<T>::load(b + (size_t)W * C),
+                                elem_traits<T>::load(b + (size_t)W * C + C)));
+    elem_traits<T>::store(y + i, m);
+  }
+}
+template <typename T>
+__global__ void maxpool_bwd_scalar(const T* __restrict__ x, const T* __restrict__ dy,
+                                   T* __restrict__ dx, int H, int W, int C, int flags) {
+  const int Ho = H / 2, Wo = W / 2;
+  const size_t total = (size_t)H * W * C;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const size_t p = i / C;
+    const int xx = (int)(p % W), yy = (int)(p / W);
+    const int oy = yy / 2, ox = xx / 2;
+    float g = 0.0f;
+    const float mine = elem_traits<T>::load(x + i);
+    if (oy < Ho && ox < Wo) {
+      int best = 0;
+      float bv = 0.0f;
+      for (int q = 0; q < 4; ++q) {
+        const float v = elem_traits<T>::load(x + ((size_t)(2 * oy + (q >> 1)) * W + 2 * ox + (q & 1)) * C + c);
+        if (q == 0 || v > bv || (v != v && bv == bv)) { bv = v; best = q; }
+      }
+      if (best == ((yy & 1) * 2 + (xx & 1))) g = elem_traits<T>::load(dy + ((size_t)oy * Wo + ox) * C + c);
+    }
+    if ((flags & STV_MASK) && !(mine > 0.0f)) g = 0.0f;
+    if (flags & STV_ACCUM) g += elem_traits<T>::load(dx + i);
+    elem_traits<T>::store(dx + i, g);
+  }
+}
+
+// -------------------------------------------------------------------- relu
+template <typename T>
+__global__ __launch_bounds__(256) void relu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, size_t n) {
+  constexpr int kVec = elem_traits<T>::kVec;
+  const size_t nv = n / kVec;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256)
+    reinterpret_cast<u32x4*>(y)[i] = relu16<T>(reinterpret_cast<const u32x4*>(x)[i]);
+  for (size_t i = nv * kVec + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    elem_traits<T>::store(y + i, fmaxf(elem_traits<T>::load(x + i), 0.0f));
+}
+template <typename T>
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                       T* __restrict__ dx, size_t n, int flags) {
+  const bool accum = (flags & STV_ACCUM) != 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    float g = (elem_traits<T>::load(x + i) > 0.0f) ? elem_traits<T>::load(dy + i) : 0.0f;
+    if (accum) g += elem_traits<T>::load(dx + i);
+    elem_traits<T>::store(dx + i, g);
+  }
+}
+
+// ----------------------------------------------------------------- content
+template <typename T>
+__global__ __launch_bounds__(256) void content_loss_kernel(const T* __restrict__ f, const T* __restrict__ t,
+                                                           float* __restrict__ part, size_t n) {
+  __shared__ float red[4];
+  float s = 0.0f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float d = elem_traits<T>::load(f + i) - elem_traits<T>::load(t + i);
+    s = fmaf(d, d, s);
+  }
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void content_grad_kernel(const T* __restrict__ f, const T* __restrict__ t,
+                                                           T* __restrict__ df, size_t n, float coef,
+                                                           const float* __restrict__ coef_dev, int flags) {
+  const float k = coef * (coef_dev ? *coef_dev : 1.0f) * (2.0f / (float)n);
+  const bool accum = (flags & STV_ACCUM) != 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    float g = k * (elem_traits<T>::load(f + i) - elem_traits<T>::load(t + i));
+    if (accum) g += elem_traits<T>::load(df + i);
+    elem_traits<T>::store(df + i, g);
+  }
+}
+
+// ------------------------------------------------------------ score combine
+// One wave.  losses[k] = scale[k] * sum(parts[off..off+cnt)); then the
+// reference's sequential fp32 stack().sum() per kind and the weighted total.
+__global__ void loss_combine_kernel(const float* __restrict__ parts, const int32_t* __restrict__ table,
+                                    const float* __restrict__ scale, int n_terms, float style_w,
+                                    float content_w, float* __restrict__ losses, float* __restrict__ scores) {
+  const int lane = threadIdx.x;
+  for (int k = 0; k < n_terms; ++k) {
+    const int off = table[3 * k], cnt = table[3 * k + 1];
+    double s = 0.0;
+    for (int i = lane; i < cnt; i += 64) s += (double)parts[off + i];
+    s = wave_sum_d(s);
+    if (lane == 0) losses[k] = (float)(s * (double)scale[k]);
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (lane == 0) {
+    float style = 0.0f, content = 0.0f;
+    for (int k = 0; k < n_terms; ++k) {
+      if (table[3 * k + 2] == 0) style += losses[k];
+      else content += losses[k];
+    }
+    const float total = style_w * style + content_w * content;
+    scores[0] = style;
+    scores[1] = content;
+    scores[2] = total;
+    scores[3] = (isfinite(style) && isfinite(content) && isfinite(total)) ? 1.0f : 0.0f;
+  }
+}
+
+template <typename T>
+int pool_fwd_typed(const void* x, void* y, int H, int W, int C, hipStream_t st) {
+  const size_t outs = (size_t)(H / 2) * (W / 2) * C;
+  if (outs == 0) return STV_OK;
+  if (C % elem_traits<T>::kVec == 0)
+    hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(grid_for(outs / elem_traits<T>::kVec)), dim3(256), 0,
+                       st, static_cast<const T*>(x), static_cast<T*>(y), H, W, C);
+  else
+    hipLaunchKernelGGL(maxpool_fwd_scalar<T>, dim3(grid_for(outs)), dim3(256), 0, st,
+                       static_cast<const T*>(x), static_cast<T*>(y), H, W, C);
+  STV_CHECK_LAUNCH();
+  return STV_OK;
+}
+template <typename T>
+int pool_bwd_typed(const void* x, const void* dy, void* dx, int H, int W, int C, int flags, hipStream_t st) {
+  if (C % elem_traits<T>::kVec == 0) {
+    const size_t items = (size_t)((H + 1) / 2) * ((W + 1) / 2) * (C / elem_traits<T>::kVec);
+    hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(grid_for(items)), dim3(256), 0, st,
+                       static_cast<const T*>(x), static_cast<const T*>(dy), static_cast<T*>(dx), H, W, C, flags);
+  } else {
+    hipLaunchKernelGGL(maxpool_bwd_scalar<T>, dim3(grid_for((size_t)H * W * C)), dim3(256), 0, st,
+                       static_cast<const T*>(x), static_cast<const T*>(dy), static_cast<T*>(dx), H, W, C, flags);
+  }
+  STV_CHECK_LAUNCH();
+  return STV_OK;
+}
+
+}  // namespace
+
+extern "C" int stv_maxpool_fwd(const void* x, void* y, int H, int W, int C, int dtype, void* stream) {
+  if (!x || !y || H <= 0 || W <= 0 || C <= 0) return STV_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == STV_F32) return pool_fwd_typed<float>(x, y, H, W, C, st);
+  if (dtype == STV_BF16) return pool_fwd_typed<bf16_t>(x, y, H, W, C, st);
+  return STV_ERR_ARG;
+}
+extern "C" int stv_maxpool_bwd(const void* x, const void* dy, void* dx, int H, int W, int C, int flags,
+                               int dtype, void* stream) {
+  if (!x || !dy || !dx || H <= 0 || W <= 0 || C <= 0) return STV_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == STV_F32) return pool_bwd_typed<float>(x, dy, dx, H, W, C, flags, st);
+  if (dtype == STV_BF16) return pool_bwd_typed<bf16_t>(x, dy, dx, H, W, C, flags, st);
+  return STV_ERR_ARG;
+}
+
+extern "C" int stv_relu_fwd(const void* x, void* y, size_t n, int dtype, void* stream) {
+  if (!x || !y) return STV_ERR_ARG;
+  if (n == 0) return STV_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == STV_F32)
+    hipLaunchKernelGGL(relu_fwd_kernel<float>, dim3(grid_for(n / 4 + 1)), dim3(256), 0, st,
+                       static_cast<const float*>(x), static_cast<float*>(y), n);
+  else if (dtype == STV_BF16)
+    hipLaunchKernelGGL(relu_fwd_kernel<bf16_t>, dim3(grid_for(n / 8 + 1)), dim3(256), 0, st,
+                       static_cast<const bf16_t*>(x), static_cast<bf16_t*>(y), n);
+  else
+    return STV_ERR_ARG;
+  STV_CHECK_LAUNCH();
+  return STV_OK;
+}
+extern "C" int stv_relu_bwd(const void* x, const void* dy, void* dx, size_t n, int flags, int dtype,
+                            void* stream) {
+  if (!x || !dy || !dx) return STV_ERR_ARG;
+  if (n == 0) return STV_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == STV_F32)
+    hipLaunchKernelGGL(relu_bwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st,
+                       static_cast<const float*>(x), static_cast<const float*>(dy), static_cast<float*>(dx), n, flags);
+  else if (dtype == STV_BF16)
+    hipLaunchKernelGGL(relu_bwd_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st,
+                       static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(dy), static_cast<bf16_t*>(dx), n, flags);
+  else
+    return STV_ERR_ARG;
+  STV_CHECK_LAUNCH();
+  return STV_OK;
+}
+
+extern "C" int stv_content_loss(const void* F, const void* target, float* loss_part, size_t n, int dtype,
+                                void* stream) {
+  if (!F || !target || !loss_part || n == 0) return STV_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == STV_F32)
+    hipLaunchKernelGGL(content_loss_kernel<float>, dim3(STV_CONTENT_LOSS_PARTS), dim3(256), 0, st,
+                       static_cast<const float*>(F), static_cast<const float*>(target), loss_part, n);
+  else if (dtype == STV_BF16)
+    hipLaunchKernelGGL(content_loss_kernel<bf16_t>, dim3(STV_CONTENT_LOSS_PARTS), dim3(256), 0, st,
+                       static_cast<const bf16_t*>(F), static_cast<const bf16_t*>(target), loss_part, n);
+  else
+    return STV_ERR_ARG;
+  STV_CHECK_LAUNCH();
+  return STV_OK;
+}
+extern "C" int stv_content_grad(const void* F, const void* target, void* dF, size_t n, float coef,
+                                const float* coef_dev, int flags, int dtype, void* stream) {
+  if (!F || !target || !dF || n == 0) return STV_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == STV_F32)
+    hipLaunchKernelGGL(content_grad_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st,
+                       static_cast<const float*>(F), static_cast<const float*>(target),
+                       static_cast<float*>(dF), n, coef, coef_dev, flags);
+  else if (dtype == STV_BF16)
+    hipLaunchKernelGGL(content_grad_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st,
+                       static_cast<const bf16_t*>(F), static_cast<const bf16_t*>(target),
+                       static_cast<bf16_t*>(dF), n, coef, coef_dev, flags);
+  else
+    return STV_ERR_ARG;
+  STV_CHECK_LAUNCH();
+  return STV_OK;
+}
+
+extern "C" int stv_loss_combine(const float* parts, const int32_t* table, const float* scale, int n_terms,
+                                float style_w, float content_w, float* losses, float* scores, void* stream) {
+  if (!parts || !table || !scale || !losses || !scores || n_terms < 0) return STV_ERR_ARG;
+  hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), parts,
+                     table, scale, n_terms, style_w, content_w, losses, scores);
+  STV_CHECK_LAUNCH();
+  return STV_OK;
+}

@@ -1,0 +1,125 @@
+// Command-buffer executor: the host (plan.py) lowers a model's forward +
+// backward schedule to a flat array of stv_op_t once; every optimisation step
+// then costs one call that enqueues all kernels from C++, or - with use_graph -
+// one hipGraphLaunch of the schedule captured on first use.
+#include <vector>
+
+#include "stv_common.h"
+
+struct stv_program {
+  std::vector<stv_op_t> ops;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  hipStream_t captured_on = nullptr;
+};
+
+namespace {
+
+int run_op(const stv_op_t& o, void* st) {
+  switch (o.op) {
+    case STV_OP_CONV_FIRST_FWD:
+      return stv_conv_first_fwd(static_cast<const float*>(o.p0), static_cast<const float*>(o.p1),
+                                static_cast<const float*>(o.p2), o.q0, o.H, o.W, o.cin, o.cout, o.dtype, st);
+    case STV_OP_CONV_FIRST_DGRAD:
+      return stv_conv_first_dgrad(o.p0, static_cast<const float*>(o.p1), static_cast<float*>(o.q0), o.H,
+                                  o.W, o.cin, o.cout, o.dtype, st);
+    case STV_OP_CONV:
+      return stv_conv_igemm(o.p0, o.p1, static_cast<const float*>(o.p2), o.p3, o.q0, o.H, o.W, o.cin,
+                            o.cout, o.taps, o.flags, o.dtype, st);
+    case STV_OP_POOL_FWD:
+      return stv_maxpool_fwd(o.p0, o.q0, o.H, o.W, o.cin, o.dtype, st);
+    case STV_OP_POOL_BWD:
+      return stv_maxpool_bwd(o.p0, o.p1, o.q0, o.H, o.W, o.cin, o.flags, o.dtype, st);
+    case STV_OP_RELU_FWD:
+      return stv_relu_fwd(o.p0, o.q0, (size_t)o.n, o.dtype, st);
+    case STV_OP_RELU_BWD:
+      return stv_relu_bwd(o.p0, o.p1, o.q0, (size_t)o.n, o.flags, o.dtype, st);
+    case STV_OP_GRAM_PARTIAL:
+      return stv_gram_partial(o.p0, static_cast<float*>(o.q0), (int)o.n, o.cin, o.dtype, st);
+    case STV_OP_GRAM_FINISH:
+      // p0 partials, p1 target, p2 coef_dev; q0 gram_out, q1 loss_part, q2 sgrad
+      // f0 clamp_max, f1 norm, f2 coef
+      return stv_gram_finish(static_cast<const float*>(o.p0), static_cast<const float*>(o.p1),
+                             static_cast<float*>(o.q0), static_cast<float*>(o.q1), o.q2, (int)o.n, o.cin,
+                             o.f0, o.f1, o.f2, static_cast<const float*>(o.p2), o.dtype, st);
+    case STV_OP_CONTENT_LOSS:
+      return stv_content_loss(o.p0, o.p1, static_cast<float*>(o.q0), (size_t)o.n, o.dtype, st);
+    case STV_OP_CONTENT_GRAD:
+      return stv_content_grad(o.p0, o.p1, o.q0, (size_t)o.n, o.f0, static_cast<const float*>(o.p2), o.flags,
+                              o.dtype, st);
+    case STV_OP_LOSS_COMBINE:
+      // p0 parts, p1 table, p2 scale; q0 losses, q1 scores; cin = n_terms; f0 style_w, f1 content_w
+      return stv_loss_combine(static_cast<const float*>(o.p0), static_cast<const int32_t*>(o.p1),
+                              static_cast<const float*>(o.p2), o.cin, o.f0, o.f1,
+                              static_cast<float*>(o.q0), static_cast<float*>(o.q1), st);
+    case STV_OP_MEMSET:
+      if (hipMemsetAsync(o.q0, 0, (size_t)o.n, static_cast<hipStream_t>(st)) != hipSuccess)
+        return STV_ERR_LAUNCH;
+      return STV_OK;
+    default:
+      return STV_ERR_ARG;
+  }
+}
+
+int run_all(const stv_program* p, void* st) {
+  for (const stv_op_t& o : p->ops) {
+    const int rc = run_op(o, st);
+    if (rc != STV_OK) return rc;
+  }
+  return STV_OK;
+}
+
+}  // namespace
+
+extern "C" int stv_version(void) { return 100; }
+
+extern "C" int stv_program_create(const stv_op_t* ops, int n_ops, stv_program** out) {
+  if (!ops || n_ops <= 0 || !out) return STV_ERR_ARG;
+  stv_program* p = new (std::nothrow) stv_program();
+  if (!p) return STV_ERR_ALLOC;
+  p->ops.assign(ops, ops + n_ops);
+  *out = p;
+  return STV_OK;
+}
+
+extern "C" int stv_program_run(stv_program* prog, int use_graph, void* stream) {
+  if (!prog) return STV_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (!use_graph) return run_all(prog, stream);
+  if (prog->exec && prog->captured_on != st) {
+    (void)hipGraphExecDestroy(prog->exec);
+    (void)hipGraphDestroy(prog->graph);
+    prog->exec = nullptr;
+    prog->graph = nullptr;
+  }
+  if (!prog->exec) {
+    // Eager warm-up first: one-time hipFuncSetAttribute calls must not land inside a capture.
+    int rc = run_all(prog, stream);
+    if (rc != STV_OK) return rc;
+    if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) return STV_ERR_GRAPH;
+    rc = run_all(prog, stream);
+    hipGraph_t g = nullptr;
+    if (hipStreamEndCapture(st, &g) != hipSuccess || rc != STV_OK) {
+      if (g) (void)hipGraphDestroy(g);
+      return rc != STV_OK ? rc : STV_ERR_GRAPH;
+    }
+    hipGraphExec_t e = nullptr;
+    if (hipGraphInstantiate(&e, g, nullptr, nullptr, 0) != hipSuccess) {
+      (void)hipGraphDestroy(g);
+      return STV_ERR_GRAPH;
+    }
+    prog->graph = g;
+    prog->exec = e;
+    prog->captured_on = st;
+    return STV_OK;  // the warm-up run already produced this call's results
+  }
+  if (hipGraphLaunch(prog->exec, st) != hipSuccess) return STV_ERR_GRAPH;
+  return STV_OK;
+}
+
+extern "C" void stv_program_destroy(stv_program* prog) {
+  if (!prog) return;
+  if (prog->exec) (void)hipGraphExecDestroy(prog->exec);
+  if (prog->graph) (void)hipGraphDestroy(prog->graph);
+  delete prog;
+}

@@ -1,0 +1,132 @@
+// Shared device/host helpers for the MI355X (gfx950) style-transfer kernels.
+// Wavefront = 64 lanes everywhere; no portability layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/stv.h"
+
+typedef uint16_t bf16_t;  // raw bf16 storage
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8v;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+#define STV_WAVE 64
+
+#define STV_CHECK_LAUNCH()                                   \
+  do {                                                       \
+    hipError_t e__ = hipGetLastError();                      \
+    if (e__ != hipSuccess) return STV_ERR_LAUNCH;            \
+  } while (0)
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) {
+  return __uint_as_float(((uint32_t)v) << 16);
+}
+
+// round-to-nearest-even; NaN stays NaN (hipcc emits v_cvt_pk_bf16_f32 for the cast)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  __bf16 b = (__bf16)f;
+  return *reinterpret_cast<bf16_t*>(&b);
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+// ReLU on two packed bf16 values: clear each half whose sign bit is set.
+__device__ __forceinline__ uint32_t relu_bf16x2(uint32_t w) {
+  uint32_t s = (w >> 15) & 0x00010001u;  // 1 per negative half
+  uint32_t m = s * 0xFFFFu;              // 0xFFFF per negative half
+  return w & ~m;
+}
+
+template <typename T> struct elem_traits;
+template <> struct elem_traits<float> {
+  static constexpr int kVec = 4;  // elements per 16-byte vector
+  static constexpr int kDtype = STV_F32;
+  __device__ static __forceinline__ float load(const float* p) { return *p; }
+  __device__ static __forceinline__ void store(float* p, float v) { *p = v; }
+};
+template <> struct elem_traits<bf16_t> {
+  static constexpr int kVec = 8;
+  static constexpr int kDtype = STV_BF16;
+  __device__ static __forceinline__ float load(const bf16_t* p) { return bf16_to_f32(*p); }
+  __device__ static __forceinline__ void store(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+// Unpack a 16-byte vector of T into floats (4 for f32, 8 for bf16).
+template <typename T> __device__ __forceinline__ void unpack16(const u32x4& v, float* f);
+template <> __device__ __forceinline__ void unpack16<float>(const u32x4& v, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) f[i] = __uint_as_float(v[i]);
+}
+template <> __device__ __forceinline__ void unpack16<bf16_t>(const u32x4& v, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __uint_as_float(v[i] << 16);
+    f[2 * i + 1] = __uint_as_float(v[i] & 0xFFFF0000u);
+  }
+}
+template <typename T> __device__ __forceinline__ u32x4 pack16(const float* f);
+template <> __device__ __forceinline__ u32x4 pack16<float>(const float* f) {
+  u32x4 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = __float_as_uint(f[i]);
+  return v;
+}
+template <> __device__ __forceinline__ u32x4 pack16<bf16_t>(const float* f) {
+  u32x4 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
+  return v;
+}
+
+template <typename T> __device__ __forceinline__ u32x4 relu16(u32x4 v);
+template <> __device__ __forceinline__ u32x4 relu16<float>(u32x4 v) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = __float_as_uint(fmaxf(__uint_as_float(v[i]), 0.0f));
+  return v;
+}
+template <> __device__ __forceinline__ u32x4 relu16<bf16_t>(u32x4 v) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = relu_bf16x2(v[i]);
+  return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Block-wide sum for blockDim.x == 256 (4 waves); result valid in every thread.
+__device__ __forceinline__ float block_sum_256(float v, float* smem4) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) smem4[w] = v;
+  __syncthreads();
+  return (smem4[0] + smem4[1]) + (smem4[2] + smem4[3]);
+}
+__device__ __forceinline__ float block_max_256(float v, float* smem4) {
+  v = wave_max(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) smem4[w] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(smem4[0], smem4[1]), fmaxf(smem4[2], smem4[3]));
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

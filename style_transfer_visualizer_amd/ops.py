@@ -1,0 +1,227 @@
+"""Tensor-level wrappers over the C ABI (``include/stv.h``).
+
+PyTorch is used only to own device memory and the current HIP stream; every
+function here enqueues hand-written HIP kernels from ``libstv_hip.so`` and
+raises ``RuntimeError`` if the library is missing or a call fails.
+
+Layouts: activations are NHWC ``[H, W, C]`` tensors (batch 1) of dtype
+float32 or bfloat16; the image / its gradient are ``[1, 3, H, W]`` float32.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import ACCUM, MASK, RELU_IN, RELU_OUT, STV_BF16, STV_F32  # noqa: F401
+
+
+def dtype_code(dtype: torch.dtype) -> int:
+    if dtype == torch.float32:
+        return STV_F32
+    if dtype == torch.bfloat16:
+        return STV_BF16
+    msg = f"unsupported activation dtype {dtype}; use torch.float32 or torch.bfloat16"
+    raise RuntimeError(msg)
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: torch.Tensor | None) -> int | None:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        msg = "libstv_hip operates on device memory only (tensor is on CPU); there is no CPU fallback"
+        raise RuntimeError(msg)
+    if not t.is_contiguous():
+        msg = "libstv_hip expects contiguous tensors"
+        raise RuntimeError(msg)
+    return t.data_ptr()
+
+
+# ---- weight packing (once, at model build; not on the per-step path) ---------
+
+def pack_weights_fwd(w: torch.Tensor) -> torch.Tensor:
+    """[Cout,Cin,3,3] -> [9,Cout,Cin], tap = ky*3+kx (K-contiguous rows)."""
+    cout, cin = w.shape[:2]
+    return w.permute(2, 3, 0, 1).reshape(9, cout, cin).contiguous()
+
+
+def pack_weights_bwd(w: torch.Tensor) -> torch.Tensor:
+    """[Cout,Cin,3,3] -> [9,Cin,Cout] with flipped taps: dgrad as a forward conv."""
+    cout, cin = w.shape[:2]
+    return w.flip(2, 3).permute(2, 3, 1, 0).reshape(9, cin, cout).contiguous()
+
+
+def to_nhwc(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """[1,C,H,W] -> [H,W,C] (test/fixture helper; the product never converts activations)."""
+    return x[0].permute(1, 2, 0).contiguous().to(dtype)
+
+
+def from_nhwc(x: torch.Tensor) -> torch.Tensor:
+    return x.permute(2, 0, 1).unsqueeze(0).float().contiguous()
+
+
+# ---- conv ---------------------------------------------------------------------
+
+def conv_first_fwd(x_nchw: torch.Tensor, wf: torch.Tensor, bias: torch.Tensor | None,
+                   dtype: torch.dtype, out: torch.Tensor | None = None) -> torch.Tensor:
+    _, cin, H, W = x_nchw.shape
+    cout = wf.shape[1]
+    if out is None:
+        out = torch.empty(H, W, cout, device=x_nchw.device, dtype=dtype)
+    lib = _lib.load()
+    _lib.check(lib.stv_conv_first_fwd(_ptr(x_nchw), _ptr(wf), _ptr(bias), _ptr(out), H, W, cin, cout,
+                                      dtype_code(dtype), _stream()), "stv_conv_first_fwd")
+    return out
+
+
+def conv_first_dgrad(dy: torch.Tensor, wf: torch.Tensor, cin: int,
+                     out: torch.Tensor | None = None) -> torch.Tensor:
+    H, W, cout = dy.shape
+    if out is None:
+        out = torch.empty(1, cin, H, W, device=dy.device, dtype=torch.float32)
+    lib = _lib.load()
+    _lib.check(lib.stv_conv_first_dgrad(_ptr(dy), _ptr(wf), _ptr(out), H, W, cin, cout,
+                                        dtype_code(dy.dtype), _stream()), "stv_conv_first_dgrad")
+    return out
+
+
+def conv_igemm(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None,
+               ref: torch.Tensor | None = None, out: torch.Tensor | None = None,
+               flags: int = 0) -> torch.Tensor:
+    """x [H,W,Cin], w [taps,Cout,Cin] (same dtype) -> [H,W,Cout]."""
+    H, W, cin = x.shape
+    taps, cout, cin_w = w.shape
+    if cin_w != cin or w.dtype != x.dtype:
+        msg = f"weight {tuple(w.shape)}/{w.dtype} does not match input {tuple(x.shape)}/{x.dtype}"
+        raise RuntimeError(msg)
+    if out is None:
+        if flags & ACCUM:
+            msg = "ACCUM needs an existing output tensor"
+            raise RuntimeError(msg)
+        out = torch.empty(H, W, cout, device=x.device, dtype=x.dtype)
+    lib = _lib.load()
+    _lib.check(lib.stv_conv_igemm(_ptr(x), _ptr(w), _ptr(bias), _ptr(ref), _ptr(out), H, W, cin, cout,
+                                  taps, flags, dtype_code(x.dtype), _stream()), "stv_conv_igemm")
+    return out
+
+
+# ---- pool / relu --------------------------------------------------------------
+
+def maxpool_fwd(x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    H, W, C = x.shape
+    if out is None:
+        out = torch.empty(H // 2, W // 2, C, device=x.device, dtype=x.dtype)
+    lib = _lib.load()
+    _lib.check(lib.stv_maxpool_fwd(_ptr(x), _ptr(out), H, W, C, dtype_code(x.dtype), _stream()),
+               "stv_maxpool_fwd")
+    return out
+
+
+def maxpool_bwd(x: torch.Tensor, dy: torch.Tensor, out: torch.Tensor | None = None,
+                flags: int = 0) -> torch.Tensor:
+    H, W, C = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    lib = _lib.load()
+    _lib.check(lib.stv_maxpool_bwd(_ptr(x), _ptr(dy), _ptr(out), H, W, C, flags, dtype_code(x.dtype),
+                                   _stream()), "stv_maxpool_bwd")
+    return out
+
+
+def relu_fwd(x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    if out is None:
+        out = torch.empty_like(x)
+    lib = _lib.load()
+    _lib.check(lib.stv_relu_fwd(_ptr(x), _ptr(out), x.numel(), dtype_code(x.dtype), _stream()), "stv_relu_fwd")
+    return out
+
+
+def relu_bwd(x: torch.Tensor, dy: torch.Tensor, out: torch.Tensor | None = None, flags: int = 0) -> torch.Tensor:
+    if out is None:
+        out = torch.empty_like(x)
+    lib = _lib.load()
+    _lib.check(lib.stv_relu_bwd(_ptr(x), _ptr(dy), _ptr(out), x.numel(), flags, dtype_code(x.dtype), _stream()),
+               "stv_relu_bwd")
+    return out
+
+
+# ---- gram / content -------------------------------------------------------------
+
+def gram_ksplit(n_pixels: int, C: int) -> int:
+    return _lib.load().stv_gram_ksplit(n_pixels, C)
+
+
+def gram_loss_parts(C: int) -> int:
+    return _lib.load().stv_gram_loss_parts(C)
+
+
+def gram_partial(F: torch.Tensor, partials: torch.Tensor | None = None) -> torch.Tensor:
+    """F [H,W,C] (or [N,C]) -> fp32 partial slabs [ksplit,C,C]."""
+    C = F.shape[-1]
+    n = F.numel() // C
+    if partials is None:
+        partials = torch.empty(gram_ksplit(n, C), C, C, device=F.device, dtype=torch.float32)
+    lib = _lib.load()
+    _lib.check(lib.stv_gram_partial(_ptr(F), _ptr(partials), n, C, dtype_code(F.dtype), _stream()),
+               "stv_gram_partial")
+    return partials
+
+
+def gram_finish(partials: torch.Tensor, n_pixels: int, C: int, *, target: torch.Tensor | None = None,
+                gram_out: torch.Tensor | None = None, loss_part: torch.Tensor | None = None,
+                sgrad: torch.Tensor | None = None, clamp_max: float = 5e5, coef: float = 1.0,
+                coef_dev: torch.Tensor | None = None, dtype: torch.dtype = torch.float32) -> None:
+    lib = _lib.load()
+    _lib.check(lib.stv_gram_finish(_ptr(partials), _ptr(target), _ptr(gram_out), _ptr(loss_part), _ptr(sgrad),
+                                   n_pixels, C, clamp_max, float(C * n_pixels), coef, _ptr(coef_dev),
+                                   dtype_code(dtype), _stream()), "stv_gram_finish")
+
+
+def content_loss(F: torch.Tensor, target: torch.Tensor, loss_part: torch.Tensor) -> None:
+    lib = _lib.load()
+    _lib.check(lib.stv_content_loss(_ptr(F), _ptr(target), _ptr(loss_part), F.numel(), dtype_code(F.dtype),
+                                    _stream()), "stv_content_loss")
+
+
+def content_grad(F: torch.Tensor, target: torch.Tensor, dF: torch.Tensor, coef: float,
+                 coef_dev: torch.Tensor | None = None, flags: int = 0) -> None:
+    lib = _lib.load()
+    _lib.check(lib.stv_content_grad(_ptr(F), _ptr(target), _ptr(dF), F.numel(), coef, _ptr(coef_dev), flags,
+                                    dtype_code(F.dtype), _stream()), "stv_content_grad")
+
+
+def loss_combine(parts: torch.Tensor, table: torch.Tensor, scale: torch.Tensor, style_w: float,
+                 content_w: float, losses: torch.Tensor, scores: torch.Tensor) -> None:
+    lib = _lib.load()
+    _lib.check(lib.stv_loss_combine(_ptr(parts), _ptr(table), _ptr(scale), table.shape[0], style_w, content_w,
+                                    _ptr(losses), _ptr(scores), _stream()), "stv_loss_combine")
+
+
+# ---- optimizers ---------------------------------------------------------------
+
+def lbfgs_alloc(n: int, history: int, device: torch.device) -> tuple[torch.Tensor, torch.Tensor]:
+    lib = _lib.load()
+    state = torch.zeros(lib.stv_lbfgs_state_bytes(history), dtype=torch.uint8, device=device)
+    ws_bytes = lib.stv_lbfgs_workspace_bytes(n, history)
+    work = torch.zeros((ws_bytes + 3) // 4, dtype=torch.float32, device=device)
+    return state, work
+
+
+def lbfgs_step(x: torch.Tensor, grad: torch.Tensor, state: torch.Tensor, work: torch.Tensor, history: int,
+               m_max: int, lr: float, tol_grad: float = 1e-7, tol_change: float = 1e-9) -> None:
+    lib = _lib.load()
+    _lib.check(lib.stv_lbfgs_step(_ptr(x), _ptr(grad), _ptr(state), _ptr(work), x.numel(), history, m_max, lr,
+                                  tol_grad, tol_change, _stream()), "stv_lbfgs_step")
+
+
+def adam_step(x: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, step: int,
+              lr: float = 1e-3, betas: tuple[float, float] = (0.9, 0.999), eps: float = 1e-8) -> None:
+    b1, b2 = betas
+    bc1 = 1 - b1 ** step
+    bc2_sqrt = (1 - b2 ** step) ** 0.5
+    lib = _lib.load()
+    _lib.check(lib.stv_adam_step(_ptr(x), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), x.numel(), lr, 1 - b1, b2,
+                                 1 - b2, eps, bc1, bc2_sqrt, _stream()), "stv_adam_step")

@@ -1,0 +1,309 @@
+"""Per-kernel parity on a real MI355X: every C-ABI entry point vs the CPU oracle.
+
+fp32 storage: results must agree with the torch-CPU fp32 oracle to rounding of
+the accumulation order (tolerances below are relative to the tensor scale).
+bf16 storage: the oracle is evaluated in fp32 on the *bf16-rounded* operands, so
+only accumulation order and the final bf16 rounding (2^-8 relative) differ.
+"""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import core_model_ref as ocm
+from oracle import optim_ref
+from style_transfer_visualizer_amd import ops, synthetic
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def rnd(shape, seed, lo=-1.0, hi=1.0):
+    n = int(np.prod(shape))
+    u = synthetic.hash_uniform(seed, 77, n).reshape(shape)
+    return torch.from_numpy((u * (hi - lo) + lo).astype(np.float32))
+
+
+def q(t, dtype):
+    """Round to the storage dtype and come back to fp32 (oracle operand)."""
+    return t.to(dtype).float()
+
+
+def tol(dtype, k_terms=1):
+    if dtype == torch.float32:
+        return 2e-6 * max(1.0, k_terms ** 0.5)
+    return 6e-3
+
+
+def assert_close(got, ref, dtype, k_terms=1, what=""):
+    got = got.float().cpu()
+    scale = float(ref.abs().max()) + 1e-30
+    err = float((got - ref).abs().max()) / scale
+    assert err <= tol(dtype, k_terms), f"{what}: rel-to-scale err {err:.3e} > {tol(dtype, k_terms):.3e}"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("hw", [(40, 72), (5, 7), (64, 64)])
+def test_conv_first_fwd_and_dgrad(dtype, hw):
+    H, W = hw
+    cout = 64
+    x = rnd((1, 3, H, W), 1, -2, 2)
+    w = rnd((cout, 3, 3, 3), 2, -0.5, 0.5)
+    b = rnd((cout,), 3, -0.1, 0.1)
+    ref = F.conv2d(x, w, b, padding=1)
+    wf = ops.pack_weights_fwd(w).to(DEV)
+    y = ops.conv_first_fwd(x.to(DEV), wf, b.to(DEV), dtype)
+    assert y.shape == (H, W, cout)
+    assert_close(ops.from_nhwc(y), ref, dtype, 27, "conv_first_fwd")
+    # dgrad: dx = conv_transpose(dy, w)
+    dy = rnd((1, cout, H, W), 4)
+    dyq = q(dy, dtype)
+    xr = x.clone().requires_grad_(True)
+    F.conv2d(xr, w, None, padding=1).backward(dyq)
+    dx = ops.conv_first_dgrad(ops.to_nhwc(dy, dtype).to(DEV), wf, 3)
+    assert_close(dx, xr.grad, torch.float32, 9 * cout, "conv_first_dgrad")
+
+
+CONV_CASES = [
+    # cin, cout, H, W
+    (64, 64, 33, 70),
+    (64, 128, 16, 40),
+    (128, 128, 9, 33),
+    (256, 512, 8, 8),
+    (512, 512, 4, 4),
+    (16, 8, 12, 20),
+    (8, 16, 12, 20),
+    (128, 256, 2, 3),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("flags", [0, ops.RELU_IN, ops.RELU_OUT, ops.RELU_IN | ops.RELU_OUT])
+def test_conv_igemm_forward(dtype, case, flags):
+    cin, cout, H, W = case
+    x = rnd((1, cin, H, W), 11)
+    w = rnd((cout, cin, 3, 3), 12, -1, 1) * (2.0 / (9 * cin)) ** 0.5
+    b = rnd((cout,), 13, -0.2, 0.2)
+    xq, wq = q(x, dtype), q(w, dtype)
+    xin = F.relu(xq) if flags & ops.RELU_IN else xq
+    ref = F.conv2d(xin, wq, b, padding=1)
+    if flags & ops.RELU_OUT:
+        ref = F.relu(ref)
+    y = ops.conv_igemm(ops.to_nhwc(x, dtype).to(DEV), ops.pack_weights_fwd(w).to(dtype).to(DEV),
+                       b.to(DEV), flags=flags)
+    assert_close(ops.from_nhwc(y), ref, dtype, 9 * cin, f"conv fwd {case} flags={flags}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_igemm_dgrad_mask_accum(dtype, case):
+    cin, cout, H, W = case
+    w = rnd((cout, cin, 3, 3), 21, -1, 1) * (2.0 / (9 * cin)) ** 0.5
+    dy = rnd((1, cout, H, W), 22)
+    zref = rnd((1, cin, H, W), 23)        # stored activation whose ReLU mask applies
+    prev = rnd((1, cin, H, W), 24)        # gradient already in the buffer (ACCUM)
+    wq, dyq, zq, pq = q(w, dtype), q(dy, dtype), q(zref, dtype), q(prev, dtype)
+    xr = torch.zeros(1, cin, H, W, requires_grad=True)
+    F.conv2d(xr, wq, None, padding=1).backward(dyq)
+    ref = xr.grad * (zq > 0).float() + pq
+    out = ops.to_nhwc(prev, dtype).to(DEV)
+    ops.conv_igemm(ops.to_nhwc(dy, dtype).to(DEV), ops.pack_weights_bwd(w).to(dtype).to(DEV), None,
+                   ref=ops.to_nhwc(zref, dtype).to(DEV), out=out, flags=ops.MASK | ops.ACCUM)
+    assert_close(ops.from_nhwc(out), ref, dtype, 9 * cout, f"dgrad {case}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C,H,W", [(64, 20, 36), (128, 8, 40), (256, 5, 9), (8, 6, 10)])
+def test_conv_1x1_as_gram_backward(dtype, C, H, W):
+    f = rnd((H, W, C), 31)
+    s = rnd((C, C), 32, -0.01, 0.01)
+    s = (s + s.t()) * 0.5
+    fq, sq = q(f, dtype), q(s, dtype)
+    ref = (fq.reshape(-1, C) @ sq.t()).reshape(H, W, C)
+    out = ops.conv_igemm(f.to(dtype).to(DEV), s.reshape(1, C, C).to(dtype).to(DEV), None)
+    got = out.float().cpu()
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) / scale <= tol(dtype, C)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("hwc", [(8, 12, 64), (7, 9, 16), (6, 6, 4), (32, 32, 128)])
+def test_maxpool_forward_backward(dtype, hwc):
+    H, W, C = hwc
+    x = rnd((1, C, H, W), 41)
+    x = torch.where(x < -0.3, torch.zeros_like(x), x)   # plenty of exact ties at 0
+    x[0, :, :2, :2] = 0.5                                # positive ties: first max must win
+    xq = q(x, dtype)
+    xr = xq.clone().requires_grad_(True)
+    y_ref = F.max_pool2d(xr, 2, 2)
+    dy = rnd(tuple(y_ref.shape), 42)
+    dyq = q(dy, dtype)
+    y_ref.backward(dyq)
+    xd = ops.to_nhwc(x, dtype).to(DEV)
+    y = ops.maxpool_fwd(xd)
+    assert torch.equal(ops.from_nhwc(y).cpu(), y_ref.detach())
+    dx = ops.maxpool_bwd(xd, ops.to_nhwc(dy, dtype).to(DEV))
+    assert torch.equal(ops.from_nhwc(dx).cpu(), xr.grad)
+    # fused ReLU mask + accumulate
+    prev = q(rnd((1, C, H, W), 43), dtype)
+    out = ops.to_nhwc(prev, dtype).to(DEV)
+    ops.maxpool_bwd(xd, ops.to_nhwc(dy, dtype).to(DEV), out=out, flags=ops.MASK | ops.ACCUM)
+    ref = q(xr.grad * (xq > 0).float() + prev, dtype) if dtype == torch.bfloat16 else xr.grad * (xq > 0).float() + prev
+    assert_close(ops.from_nhwc(out), ref, dtype, 1, "maxpool_bwd mask+accum")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_relu_forward_backward(dtype):
+    x = rnd((9, 11, 20), 51)
+    dy = rnd((9, 11, 20), 52)
+    xd, dyd = x.to(dtype).to(DEV), dy.to(dtype).to(DEV)
+    assert torch.equal(ops.relu_fwd(xd).float().cpu(), F.relu(q(x, dtype)))
+    assert torch.equal(ops.relu_bwd(xd, dyd).float().cpu(), q(dy, dtype) * (q(x, dtype) > 0).float())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C,H,W,scale", [(64, 37, 53, 1.0), (128, 16, 24, 1.0), (256, 9, 11, 1.0),
+                                         (512, 8, 8, 1.0), (8, 10, 14, 1.0), (64, 64, 64, 40.0)])
+def test_gram_forward_loss_and_seed(dtype, C, H, W, scale):
+    n = H * W
+    f = rnd((1, C, H, W), 61) * scale
+    fq = q(f, dtype)
+    clamp = 5e5
+    tgt = ocm.gram_matrix(q(rnd((1, C, H, W), 62) * scale, dtype))
+    fr = fq.clone().requires_grad_(True)
+    g_ref = ocm.gram_matrix(fr, clamp)
+    loss_ref = F.mse_loss(g_ref, tgt)
+    coef = 1e5
+    (coef * loss_ref).backward()
+    raw = fq.reshape(C, n) @ fq.reshape(C, n).t()
+    if scale > 1:
+        assert int((raw > clamp).sum()) > 0, "case must engage the clamp"
+
+    fd = ops.to_nhwc(f, dtype).to(DEV)
+    partials = ops.gram_partial(fd)
+    gram = torch.empty(C, C, device=DEV)
+    parts = torch.zeros(ops.gram_loss_parts(C), device=DEV)
+    sgrad = torch.empty(C, C, device=DEV, dtype=dtype)
+    ops.gram_finish(partials, n, C, target=tgt.to(DEV), gram_out=gram, loss_part=parts, sgrad=sgrad,
+                    clamp_max=clamp, coef=coef, dtype=dtype)
+    assert_close(gram, g_ref.detach(), torch.float32, n, "gram")
+    loss = float(parts.double().sum().cpu()) / (C * C)
+    assert loss == pytest.approx(float(loss_ref), rel=1e-4)
+    # backward product dF^T = F^T S as a 1x1 conv
+    df = ops.conv_igemm(fd, sgrad.reshape(1, C, C), None)
+    ref = fr.grad
+    got = ops.from_nhwc(df).cpu()
+    err = float((got - ref).abs().max()) / (float(ref.abs().max()) + 1e-30)
+    assert err <= (1e-4 if dtype == torch.float32 else 2e-2), f"gram bwd err {err:.3e}"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_content_loss_and_grad(dtype):
+    f = rnd((17, 23, 32), 71)
+    t = rnd((17, 23, 32), 72)
+    fq, tq = q(f, dtype), q(t, dtype)
+    fr = fq.clone().requires_grad_(True)
+    loss_ref = F.mse_loss(fr, tq)
+    (3.0 * loss_ref).backward()
+    fd, td = f.to(dtype).to(DEV), t.to(dtype).to(DEV)
+    parts = torch.zeros(256, device=DEV)
+    ops.content_loss(fd, td, parts)
+    assert float(parts.double().sum().cpu()) / f.numel() == pytest.approx(float(loss_ref), rel=1e-5)
+    prev = q(rnd((17, 23, 32), 73), dtype)
+    out = prev.to(dtype).to(DEV)
+    ops.content_grad(fd, td, out, 3.0, flags=ops.ACCUM)
+    assert_close(out, fr.grad + prev, dtype, 1, "content grad")
+
+
+def test_loss_combine():
+    parts = torch.arange(1, 41, dtype=torch.float32, device=DEV)
+    table = torch.tensor([[0, 10, 0], [10, 10, 0], [20, 20, 1]], dtype=torch.int32, device=DEV)
+    scale = torch.tensor([0.5, 0.25, 2.0], device=DEV)
+    losses = torch.zeros(3, device=DEV)
+    scores = torch.zeros(4, device=DEV)
+    ops.loss_combine(parts, table, scale, 1e5, 2.0, losses, scores)
+    l = [55 * 0.5, 155 * 0.25, 610 * 2.0]
+    assert losses.cpu().tolist() == l
+    style = np.float32(l[0]) + np.float32(l[1])
+    total = np.float32(1e5) * style + np.float32(2.0) * np.float32(l[2])
+    assert scores.cpu().tolist() == [float(style), l[2], float(total), 1.0]
+
+
+def _quartic(n, seed):
+    a = rnd((n,), seed, 0.5, 2.0)
+    b = rnd((n,), seed + 1, -1.0, 1.0)
+
+    def f(x):
+        return (0.5 * a * x * x - b * x + 0.05 * x ** 4).sum() + 0.1 * (x[1:] * x[:-1]).sum()
+    return f
+
+
+@pytest.mark.parametrize("history", [4, 100])
+def test_lbfgs_step_matches_oracle(history):
+    n, steps = 20000, 14
+    f = _quartic(n, 81)
+    x_ref = torch.zeros(n)
+    ref = optim_ref.LbfgsRef(x_ref, lr=1.0, history_size=history)
+    x = torch.zeros(n, device=DEV)
+    state, work = ops.lbfgs_alloc(n, history, torch.device(DEV))
+    for step in range(steps):
+        def closure():
+            with torch.enable_grad():
+                xr = x_ref.detach().clone().requires_grad_(True)
+                loss = f(xr)
+                loss.backward()
+            return loss.detach(), xr.grad
+        ref.step(closure)
+        with torch.enable_grad():
+            xg = x.detach().cpu().clone().requires_grad_(True)
+            f(xg).backward()
+        ops.lbfgs_step(x, xg.grad.to(DEV), state, work, history, min(step, history), 1.0)
+        err = float((x.cpu() - x_ref).abs().max()) / float(x_ref.abs().max())
+        assert err < 2e-4, f"step {step + 1}: x diverged from the oracle by {err:.3e}"
+    st = state.cpu().view(torch.int32)
+    assert int(st[0]) == ref.n_iter
+    assert int(st[1]) == len(ref.old_dirs)
+
+
+def test_lbfgs_early_return_and_no_descent():
+    n = 4096
+    x = torch.ones(n, device=DEV)
+    state, work = ops.lbfgs_alloc(n, 100, torch.device(DEV))
+    tiny = torch.full((n,), 5e-8, device=DEV)           # |g|max <= 1e-7 -> return before any update
+    ops.lbfgs_step(x, tiny, state, work, 100, 0, 1.0)
+    st = state.cpu().view(torch.int32)
+    assert int(st[0]) == 0 and int(st[3]) == 1
+    assert torch.equal(x.cpu(), torch.ones(n))
+    g = torch.full((n,), 1.0, device=DEV)
+    ops.lbfgs_step(x, g, state, work, 100, 0, 1.0)       # first real step: t = min(1, 1/|g|_1)
+    st = state.cpu().view(torch.int32)
+    assert int(st[0]) == 1 and int(st[3]) == 0
+    np.testing.assert_allclose(x.cpu().numpy(), 1.0 - 1.0 / n, rtol=1e-6)
+
+
+def test_adam_step_matches_oracle():
+    n = 5000
+    f = _quartic(n, 91)
+    x_ref = rnd((n,), 93)
+    x = x_ref.clone().to(DEV)
+    ref = optim_ref.AdamRef(x_ref, lr=1e-2)
+    m = torch.zeros(n, device=DEV)
+    v = torch.zeros(n, device=DEV)
+    for step in range(1, 9):
+        def closure():
+            with torch.enable_grad():
+                xr = x_ref.detach().clone().requires_grad_(True)
+                loss = f(xr)
+                loss.backward()
+            return loss.detach(), xr.grad
+        ref.step(closure)
+        with torch.enable_grad():
+            xg = x.detach().cpu().clone().requires_grad_(True)
+            f(xg).backward()
+        ops.adam_step(x, xg.grad.to(DEV), m, v, step, lr=1e-2)
+    np.testing.assert_allclose(x.cpu().numpy(), x_ref.numpy(), rtol=1e-5, atol=1e-6)
