@@ -1,0 +1,478 @@
+"""MI355X-native model + losses behind the reference's ``core_model`` API.
+
+Public surface mirrors /root/reference/src/style_transfer_visualizer/core_model.py
+(``gram_matrix`` :29, ``initialize_input`` :66, ``initialize_vgg`` :103,
+``create_feature_blocks`` :120, ``StyleContentModel`` :149,
+``prepare_model_and_input`` :331) with the same argument meaning and error
+texts, but every forward/backward FLOP runs in hand-written HIP kernels from
+``libstv_hip.so``; PyTorch only owns memory and streams.  There is no eager or
+CPU fallback: tensors must live on the GPU and the library must be built.
+"""
+from __future__ import annotations
+
+import os
+from pathlib import Path
+from urllib.parse import urlparse
+
+import torch
+from torch import nn
+
+from . import ops, plan, synthetic
+from .constants import GRAM_MATRIX_CLAMP_MAX
+from .logging_utils import logger
+
+VGG19_WEIGHTS_URL = "https://download.pytorch.org/models/vgg19-dcbb9e9d.pth"
+_PRECISIONS = {"fp32": torch.float32, "bf16": torch.bfloat16}
+
+
+def resolve_precision(precision: str | None = None) -> torch.dtype:
+    """Activation storage dtype: fp32 = parity mode (default), bf16 = performance mode."""
+    name = precision or os.environ.get("STV_PRECISION", "fp32")
+    if name not in _PRECISIONS:
+        msg = f"Unsupported precision: {name} (expected one of {sorted(_PRECISIONS)})"
+        raise ValueError(msg)
+    return _PRECISIONS[name]
+
+
+# --------------------------------------------------------------------------- gram
+class _GramFn(torch.autograd.Function):
+    """clamp(F F^T, max)/(b*c*h*w) for an NCHW tensor, via the split-K MFMA Gram kernels."""
+
+    @staticmethod
+    def forward(ctx, tensor: torch.Tensor, clamp_max: float) -> torch.Tensor:
+        b, c, h, w = tensor.shape
+        C, n = b * c, h * w
+        if C % 4:
+            msg = f"gram_matrix kernel needs b*c to be a multiple of 4, got {C}"
+            raise RuntimeError(msg)
+        feat = tensor.detach().reshape(C, n).t().contiguous().float()     # [N, C] (NHWC view)
+        partials = ops.gram_partial(feat)
+        gram = torch.empty(C, C, device=tensor.device, dtype=torch.float32)
+        raw = torch.empty(C, C, device=tensor.device, dtype=torch.float32)
+        ops.gram_finish(partials, n, C, gram_out=gram, clamp_max=clamp_max)
+        ops.gram_finish(partials, n, C, gram_out=raw, clamp_max=float("inf"))
+        ctx.save_for_backward(feat, raw)
+        ctx.meta = (b, c, h, w, clamp_max)
+        return gram.to(tensor.dtype)
+
+    @staticmethod
+    def backward(ctx, gout: torch.Tensor):
+        feat, raw = ctx.saved_tensors
+        b, c, h, w, clamp_max = ctx.meta
+        C, n = b * c, h * w
+        norm = float(C * n)
+        seed = gout.float() * (raw * norm <= clamp_max).float() / norm
+        seed = (seed + seed.t()).contiguous()                           # dF^T = F^T (dR + dR^T)
+        d_feat = ops.conv_igemm(feat.reshape(1, n, C), seed.reshape(1, C, C))
+        return d_feat.reshape(n, C).t().reshape(b, c, h, w).to(gout.dtype), None
+
+
+def gram_matrix(tensor: torch.Tensor, clamp_max: float = GRAM_MATRIX_CLAMP_MAX) -> torch.Tensor:
+    """Gram matrix of ``[batch, channels, h, w]`` features (batch folded into channels).
+
+    Same arithmetic as reference core_model.py:56-63: ``mm(F, F.t()).clamp(max=clamp_max)``
+    then ``div(b*c*h*w)``; returns ``[b*c, b*c]``.
+    """
+    return _GramFn.apply(tensor, float(clamp_max))
+
+
+# ------------------------------------------------------------------- initialisation
+def initialize_input(content_img: torch.Tensor, method: str) -> torch.Tensor:
+    """Start image for the optimisation (reference core_model.py:66-100)."""
+    if not isinstance(content_img, torch.Tensor):
+        msg = f"Expected content_img to be a Tensor, got {type(content_img)}"
+        raise TypeError(msg)
+    if method == "content":
+        start = content_img.clone()
+    elif method == "random":
+        start = torch.randn_like(content_img)
+    elif method == "white":
+        start = torch.ones_like(content_img)
+    else:
+        msg = f"Unsupported initialization method: {method}"
+        raise ValueError(msg)
+    return start.requires_grad_(True)  # noqa: FBT003
+
+
+def build_vgg_features(weights: list[tuple[torch.Tensor, torch.Tensor]] | None = None,
+                       cfg: tuple = synthetic.VGG19_CFG) -> nn.Sequential:
+    """torchvision-free ``vgg19().features`` topology (conv3x3 pad 1 / ReLU / MaxPool 2x2)."""
+    layers: list[nn.Module] = []
+    cin = 3
+    it = iter(weights) if weights is not None else None
+    for v in cfg:
+        if v == "M":
+            layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+            continue
+        conv = nn.Conv2d(cin, int(v), kernel_size=3, padding=1)
+        if it is not None:
+            w, b = next(it)
+            with torch.no_grad():
+                conv.weight.copy_(w)
+                conv.bias.copy_(b)
+        layers += [conv, nn.ReLU(inplace=True)]
+        cin = int(v)
+    return nn.Sequential(*layers)
+
+
+def initialize_vgg() -> nn.Module:
+    """Frozen VGG19 feature stack (reference core_model.py:103-117).
+
+    Order of preference: torchvision with IMAGENET1K_V1 weights (as the
+    reference); the cached ``vgg19-dcbb9e9d.pth`` loaded into the
+    torchvision-free topology; deterministic synthetic weights when
+    ``STV_SYNTHETIC_WEIGHTS=<seed>`` is set (benchmarks / offline boxes).
+    """
+    cache_dir = Path(torch.hub.get_dir()) / "checkpoints"
+    cache_path = cache_dir / Path(urlparse(VGG19_WEIGHTS_URL).path).name
+    synth = os.environ.get("STV_SYNTHETIC_WEIGHTS")
+    if synth is not None:
+        logger.info("Using synthetic VGG19 weights (seed %s)", synth)
+        vgg = build_vgg_features(synthetic.synthetic_conv_weights(int(synth)))
+    else:
+        if cache_path.exists():
+            logger.info("Using cached VGG19 weights at %s", cache_path)
+        else:
+            logger.info("Downloading VGG19 weights to %s", cache_path)
+        try:
+            from torchvision.models import VGG19_Weights, vgg19  # noqa: PLC0415
+            vgg = vgg19(weights=VGG19_Weights.IMAGENET1K_V1).features
+        except ImportError:
+            if not cache_path.exists():
+                msg = (f"torchvision is not installed and {cache_path} is absent: place the IMAGENET1K_V1 "
+                       "checkpoint there, or set STV_SYNTHETIC_WEIGHTS=<seed> for synthetic weights.")
+                raise RuntimeError(msg) from None
+            vgg = build_vgg_features()
+            state = torch.load(cache_path, map_location="cpu", weights_only=True)
+            feats = {k[len("features."):]: v for k, v in state.items() if k.startswith("features.")}
+            vgg.load_state_dict(feats)
+    vgg = vgg.eval()
+    for p in vgg.parameters():
+        p.requires_grad_(False)  # noqa: FBT003
+    return vgg
+
+
+def create_feature_blocks(
+    vgg: nn.Module,
+    style_layers: list[int],
+    content_layers: list[int],
+) -> tuple[nn.ModuleList, list[int], list[int]]:
+    """Slice the stack after every tapped index (reference core_model.py:120-146).
+
+    Returns ``(blocks, content_ids, style_ids)``; trailing untapped layers are
+    dropped and every ReLU is made out-of-place.
+    """
+    blocks = nn.ModuleList()
+    content_ids: list[int] = []
+    style_ids: list[int] = []
+    pending = nn.Sequential()
+    for idx, layer in enumerate(vgg.children()):
+        pending.add_module(str(idx), nn.ReLU(inplace=False) if isinstance(layer, nn.ReLU) else layer)
+        hit_style, hit_content = idx in style_layers, idx in content_layers
+        if hit_style or hit_content:
+            blocks.append(pending)
+            pending = nn.Sequential()
+        if hit_style:
+            style_ids.append(len(blocks) - 1)
+        if hit_content:
+            content_ids.append(len(blocks) - 1)
+    return blocks, content_ids, style_ids
+
+
+# --------------------------------------------------------------------------- engine
+class _Engine:
+    """Buffers + command buffers for one (model, image size, device)."""
+
+    def __init__(self, layers: list[nn.Module], style_at: list[int], content_at: list[int],
+                 H: int, W: int, dtype: torch.dtype, device: torch.device) -> None:
+        self.layers, self.style_at, self.content_at = layers, style_at, content_at
+        self.H, self.W, self.dtype, self.device = H, W, dtype, device
+        self.sched = plan.Schedule(layers, style_at, content_at, H, W, dtype, device, with_grad=True)
+        s = self.sched
+        self.n_style, self.n_content = len(s.style_taps), len(s.content_taps)
+        n_terms = self.n_style + self.n_content
+        off = 0
+        rows, scale = [], []
+        for tap in s.style_taps:
+            tap.parts_off, tap.parts_cnt = off, ops.gram_loss_parts(tap.buf.C)
+            off += tap.parts_cnt
+            rows.append([tap.parts_off, tap.parts_cnt, 0])
+            scale.append(1.0 / float(tap.buf.C * tap.buf.C))
+            tap.sgrad = torch.zeros(1, tap.buf.C, tap.buf.C, device=device, dtype=dtype)
+        for tap in s.content_taps:
+            tap.parts_off, tap.parts_cnt = off, ops._lib.CONTENT_LOSS_PARTS
+            off += tap.parts_cnt
+            rows.append([tap.parts_off, tap.parts_cnt, 1])
+            scale.append(1.0 / float(tap.buf.act.numel()))
+        self.parts = torch.zeros(max(off, 1), device=device, dtype=torch.float32)
+        self.table = torch.tensor(rows, dtype=torch.int32, device=device).reshape(-1, 3)
+        self.scale = torch.tensor(scale, dtype=torch.float32, device=device)
+        self.losses = torch.zeros(max(n_terms, 1), device=device, dtype=torch.float32)
+        self.scores = torch.zeros(4, device=device, dtype=torch.float32)
+        self.coef_buf = torch.ones(max(n_terms, 1), device=device, dtype=torch.float32)
+        self._programs: dict = {}
+        self.use_graph = os.environ.get("STV_HIP_GRAPH", "1") != "0"
+
+    # -- op list pieces -------------------------------------------------------
+    def _loss_ops(self, *, style_coef: float, coef_dev: torch.Tensor | None, with_seed: bool) -> list:
+        s = self.sched
+        out = []
+        for tap in s.style_taps:
+            lp = self.parts[tap.parts_off:]
+            cd = coef_dev[tap.order:] if coef_dev is not None else None
+            out += s.gram_ops(tap, gram_out=None, target=tap.target, loss_part=lp,
+                              sgrad=tap.sgrad if with_seed else None, coef=style_coef, coef_dev=cd)
+        for tap in s.content_taps:
+            out.append(s._op(op=plan.OP_CONTENT_LOSS, p0=tap.buf.act, p1=tap.target,
+                             q0=self.parts[tap.parts_off:], n=tap.buf.act.numel()))
+        return out
+
+    def _combine_op(self, style_w: float, content_w: float):
+        return self.sched._op(op=plan.OP_LOSS_COMBINE, p0=self.parts, p1=self.table, p2=self.scale,
+                              q0=self.losses, q1=self.scores, cin=self.n_style + self.n_content,
+                              f0=style_w, f1=content_w)
+
+    def _program(self, key: tuple, builder) -> plan.Program:
+        prog = self._programs.get(key)
+        if prog is None:
+            prog = plan.Program(builder(), self.sched._keep)
+            self._programs[key] = prog
+        return prog
+
+    # -- targets ---------------------------------------------------------------
+    def capture_content(self, content_img: torch.Tensor) -> list[torch.Tensor]:
+        x = content_img.detach().contiguous().float()
+        plan.Program(self.sched.forward_ops(x), self.sched._keep + [x]).run()
+        targets = [tap.buf.act.clone() for tap in self.sched.content_taps]
+        for tap, t in zip(self.sched.content_taps, targets, strict=True):
+            tap.target = t
+        return targets
+
+    def capture_style(self, style_img: torch.Tensor) -> list[torch.Tensor]:
+        x = style_img.detach().contiguous().float()
+        Hs, Ws = x.shape[-2:]
+        sched = (self.sched if (Hs, Ws) == (self.H, self.W) else
+                 plan.Schedule(self.layers, self.style_at, self.content_at, Hs, Ws, self.dtype, self.device,
+                               with_grad=False))
+        op_list = sched.forward_ops(x)
+        grams = []
+        for tap in sched.style_taps:
+            g = torch.empty(tap.buf.C, tap.buf.C, device=self.device, dtype=torch.float32)
+            grams.append(g)
+            op_list += sched.gram_ops(tap, gram_out=g, target=None, loss_part=None, sgrad=None, coef=0.0,
+                                      coef_dev=None)
+        plan.Program(op_list, sched._keep + [x]).run()
+        for tap, g in zip(self.sched.style_taps, grams, strict=True):
+            tap.target = g
+        return grams
+
+    def bind_targets(self, style_targets: list[torch.Tensor], content_targets: list[torch.Tensor]) -> None:
+        """Re-point taps at the model's public target lists (they may have been replaced)."""
+        if len(style_targets) != self.n_style or len(content_targets) != self.n_content:
+            msg = "target lists do not match the model's style/content layers"
+            raise RuntimeError(msg)
+        changed = False
+        for tap, t in zip(self.sched.style_taps, style_targets, strict=True):
+            t = self._as_target(t, (tap.buf.C, tap.buf.C), torch.float32)
+            changed |= tap.target is None or tap.target.data_ptr() != t.data_ptr()
+            tap.target = t
+        for tap, t in zip(self.sched.content_taps, content_targets, strict=True):
+            if t.dim() == 4:    # NCHW as the reference stores it -> NHWC storage
+                t = ops.to_nhwc(t, self.dtype)
+            t = self._as_target(t, tuple(tap.buf.act.shape), self.dtype)
+            changed |= tap.target is None or tap.target.data_ptr() != t.data_ptr()
+            tap.target = t
+        if changed:
+            self._programs.clear()
+
+    def _as_target(self, t: torch.Tensor, shape: tuple, dtype: torch.dtype) -> torch.Tensor:
+        if tuple(t.shape) != shape:
+            msg = f"target shape {tuple(t.shape)} does not match features {shape}"
+            raise RuntimeError(msg)
+        if t.device != self.device or t.dtype != dtype or not t.is_contiguous():
+            t = t.to(self.device, dtype).contiguous()
+        return t
+
+    # -- execution -------------------------------------------------------------
+    def loss_and_grad(self, x: torch.Tensor, grad: torch.Tensor, style_w: float, content_w: float) -> None:
+        key = ("fused", x.data_ptr(), grad.data_ptr(), style_w, content_w)
+
+        def build():
+            s = self.sched
+            return (s.forward_ops(x) + self._loss_ops(style_coef=style_w, coef_dev=None, with_seed=True)
+                    + [self._combine_op(style_w, content_w)]
+                    + s.backward_ops(grad, style_coef=style_w, content_coef=content_w, coef_dev=None))
+        self._program(key, build).run(self.use_graph)
+
+    def forward_losses(self, x: torch.Tensor) -> None:
+        key = ("fwd", x.data_ptr())
+
+        def build():
+            return (self.sched.forward_ops(x)
+                    + self._loss_ops(style_coef=0.0, coef_dev=None, with_seed=False)
+                    + [self._combine_op(1.0, 1.0)])
+        self._program(key, build).run(self.use_graph)
+
+    def backward_from(self, gout: torch.Tensor, grad: torch.Tensor) -> None:
+        self.coef_buf.copy_(gout)
+        key = ("bwd", grad.data_ptr())
+
+        def build():
+            s = self.sched
+            seeds = []
+            for tap in s.style_taps:   # recompute the seeds with the upstream coefficients
+                seeds += s.gram_ops(tap, gram_out=None, target=tap.target, loss_part=None, sgrad=tap.sgrad,
+                                    coef=1.0, coef_dev=self.coef_buf[tap.order:], partial=False)
+            return seeds + s.backward_ops(grad, style_coef=1.0, content_coef=1.0, coef_dev=self.coef_buf)
+        self._program(key, build).run(self.use_graph)
+
+
+class _LossesFn(torch.autograd.Function):
+    """``model(x)`` for autograd users: HIP forward now, HIP backward on ``.backward()``."""
+
+    @staticmethod
+    def forward(ctx, x: torch.Tensor, engine: _Engine) -> torch.Tensor:
+        xc = x.detach()
+        if not xc.is_contiguous() or xc.dtype != torch.float32:
+            xc = xc.contiguous().float()
+        engine.forward_losses(xc)
+        ctx.engine = engine
+        ctx.x_meta = (x.shape, x.dtype)
+        return engine.losses.clone()
+
+    @staticmethod
+    def backward(ctx, gout: torch.Tensor):
+        engine: _Engine = ctx.engine
+        shape, dtype = ctx.x_meta
+        grad = torch.empty(shape, device=engine.device, dtype=torch.float32)
+        engine.backward_from(gout.contiguous().float(), grad)
+        return grad.to(dtype), None
+
+
+# ---------------------------------------------------------------------------- model
+class StyleContentModel(nn.Module):
+    """VGG19 feature extractor with Gram style losses and content MSE losses.
+
+    Same attributes as reference core_model.py:149-328 (``vgg_blocks``,
+    ``style_ids``, ``content_ids``, ``style_targets``, ``content_targets``);
+    ``forward`` returns two lists of 0-d loss tensors differentiable w.r.t. the
+    input image.  ``loss_and_grad`` is the fused fast path used by the runner.
+    """
+
+    def __init__(self, style_layers: list[int], content_layers: list[int], *,
+                 precision: str | None = None) -> None:
+        super().__init__()
+        vgg = initialize_vgg()
+        self.vgg_blocks, self.content_ids, self.style_ids = create_feature_blocks(
+            vgg, style_layers, content_layers)
+        self.style_targets: list[torch.Tensor] | None = None
+        self.content_targets: list[torch.Tensor] | None = None
+        self._style_at = sorted(set(style_layers))
+        self._content_at = sorted(set(content_layers))
+        self._dtype = resolve_precision(precision)
+        self._engines: dict = {}
+
+    # -- engine plumbing ---------------------------------------------------------
+    def _layers(self) -> list[nn.Module]:
+        return [layer for block in self.vgg_blocks for layer in block]
+
+    def _engine_for(self, x: torch.Tensor) -> _Engine:
+        if not isinstance(x, torch.Tensor) or not x.is_cuda:
+            msg = ("StyleContentModel runs on the MI355X HIP kernels only: the image must be a GPU tensor "
+                   "(there is no CPU fallback on this path).")
+            raise RuntimeError(msg)
+        if x.dim() != 4 or x.shape[0] != 1:
+            msg = f"expected an image of shape [1, C, H, W], got {tuple(x.shape)}"
+            raise RuntimeError(msg)
+        if not self._style_at and not self._content_at:
+            msg = "no style or content layers configured"
+            raise RuntimeError(msg)
+        H, W = int(x.shape[-2]), int(x.shape[-1])
+        key = (H, W, x.device.index)
+        eng = self._engines.get(key)
+        if eng is None:
+            eng = _Engine(self._layers(), self._style_at, self._content_at, H, W, self._dtype, x.device)
+            self._engines[key] = eng
+        return eng
+
+    def set_targets(self, style_img: torch.Tensor, content_img: torch.Tensor) -> None:
+        """Capture Gram targets from the style image and activations from the content image."""
+        eng = self._engine_for(content_img)
+        if not style_img.is_cuda:
+            msg = "style image must be a GPU tensor (no CPU fallback on this path)"
+            raise RuntimeError(msg)
+        self.style_targets = eng.capture_style(style_img)
+        self.content_targets = eng.capture_content(content_img)
+
+    def _require_targets(self) -> None:
+        # same order and texts as reference core_model.py:255-258, 287-290
+        if self.style_targets is None:
+            msg = "style_targets must be set before computing losses."
+            raise RuntimeError(msg)
+        if self.content_targets is None:
+            msg = "content_targets must be set before computing losses."
+            raise RuntimeError(msg)
+
+    def forward(self, x: torch.Tensor) -> tuple[list[torch.Tensor], list[torch.Tensor]]:
+        """Per-layer style and content losses for ``x`` (``[1, C, H, W]``)."""
+        self._require_targets()
+        eng = self._engine_for(x)
+        eng.bind_targets(self.style_targets, self.content_targets)
+        losses = _LossesFn.apply(x, eng)
+        style = [losses[i] for i in range(eng.n_style)]
+        content = [losses[eng.n_style + i] for i in range(eng.n_content)]
+        return style, content
+
+    def loss_and_grad(self, x: torch.Tensor, style_w: float, content_w: float,
+                      ) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """Fused step: writes d(style_w*S + content_w*C)/dx into ``x.grad``.
+
+        Equivalent to reference optimization.py:292-313 (forward, weighted sum,
+        ``loss.backward()``) in one command-buffer launch with no host sync.
+        Returns 0-d device tensors (style_score, content_score, total).
+        """
+        self._require_targets()
+        eng = self._engine_for(x)
+        eng.bind_targets(self.style_targets, self.content_targets)
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            msg = "loss_and_grad needs a contiguous float32 image"
+            raise RuntimeError(msg)
+        grad = getattr(self, "_grad_buf", None)
+        if grad is None or grad.shape != x.shape or grad.device != x.device:
+            grad = torch.zeros_like(x, requires_grad=False)
+            self._grad_buf = grad
+        eng.loss_and_grad(x.detach(), grad, float(style_w), float(content_w))
+        x.grad = grad
+        scores = eng.scores.clone()
+        return scores[0], scores[1], scores[2]
+
+
+def prepare_model_and_input(
+    content_img: torch.Tensor,
+    style_img: torch.Tensor,
+    device: torch.device,
+    optimization,
+    *,
+    precision: str | None = None,
+) -> tuple[nn.Module, torch.Tensor, torch.optim.Optimizer]:
+    """Build model, start image and optimizer (reference core_model.py:331-350).
+
+    ``precision`` (keyword-only extension): "fp32" | "bf16" activation storage;
+    default from ``STV_PRECISION`` or fp32.
+    """
+    from .optimizers import make_lbfgs  # noqa: PLC0415
+
+    model = StyleContentModel(
+        style_layers=optimization.style_layers,
+        content_layers=optimization.content_layers,
+        precision=precision,
+    ).to(device)
+    model.set_targets(style_img, content_img)
+    input_img = initialize_input(content_img, optimization.init_method)
+    optimizer = make_lbfgs(
+        input_img,
+        lr=optimization.lr,
+        max_iter=optimization.lbfgs_max_iter,
+        max_eval=optimization.lbfgs_max_eval,
+    )
+    return model, input_img, optimizer

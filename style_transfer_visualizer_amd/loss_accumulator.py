@@ -1,0 +1,109 @@
+"""Device-side loss bookkeeping with batched host synchronisation.
+
+Behaviour follows reference loss_accumulator.py:26-213: every step's
+(style, content, total) scalars are appended to a device ring buffer of
+``history_capacity`` entries; Python floats are produced only when
+``step % log_every == 0`` (or ``force``), so the optimisation loop never waits
+for the GPU in between.  Here the three series share one ``[3, capacity]``
+tensor and a flush is a single device-to-host copy.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+
+DEFAULT_HISTORY_CAPACITY = 2048
+_KEYS = ("style_loss", "content_loss", "total_loss")
+
+
+@dataclass(slots=True)
+class LoggedLoss:
+    """Loss scalars that have been copied to the host."""
+
+    step: int
+    style_loss: float
+    content_loss: float
+    total_loss: float
+
+
+class LossAccumulator:
+    """Ring-buffered loss history on the device, floats on demand."""
+
+    def __init__(self, *, log_every: int, history_capacity: int | None, track_history: bool,
+                 device: torch.device, dtype: torch.dtype) -> None:
+        self._log_every = max(1, log_every)
+        self._capacity = max(1, history_capacity or DEFAULT_HISTORY_CAPACITY)
+        self._track = track_history
+        self._device = device
+        # fp16 images keep fp16 buffers; everything else (incl. bf16) logs in fp32
+        self._buffer_dtype = torch.float16 if dtype == torch.float16 else torch.float32
+        self._ring: torch.Tensor | None = None
+        if track_history:
+            self._ring = torch.empty(3, self._capacity, dtype=self._buffer_dtype, device=device)
+        self._next = 0            # slot the next record goes to
+        self._count = 0           # valid records in the ring
+        self._records = 0         # records ever written
+        self._pending: tuple[int, torch.Tensor] | None = None
+        self._last: LoggedLoss | None = None
+
+    @property
+    def capacity(self) -> int:
+        """Maximum number of history entries kept in memory."""
+        return self._capacity
+
+    @property
+    def tracks_history(self) -> bool:
+        """True when per-step history is being recorded."""
+        return self._track
+
+    @property
+    def history_truncated(self) -> bool:
+        """True once the ring has overwritten its oldest entries."""
+        return self._records > self._capacity
+
+    def accumulate(self, step_idx: int, style_loss: torch.Tensor, content_loss: torch.Tensor,
+                   total_loss: torch.Tensor, *, force: bool = False) -> LoggedLoss | None:
+        """Record one step; return host scalars only at the logging cadence."""
+        triple = torch.stack((style_loss.detach().reshape(()), content_loss.detach().reshape(()),
+                              total_loss.detach().reshape(())))
+        self._pending = (step_idx, triple)
+        if self._track:
+            if self._ring is None:
+                msg = "History buffers are uninitialized."
+                raise RuntimeError(msg)
+            self._ring[:, self._next] = triple.to(dtype=self._buffer_dtype, device=self._device)
+            self._next = (self._next + 1) % self._capacity
+            self._count = min(self._count + 1, self._capacity)
+            self._records += 1
+        if force or step_idx % self._log_every == 0:
+            return self._sync_pending()
+        return None
+
+    def latest(self) -> LoggedLoss | None:
+        """Most recent host-synced scalars."""
+        return self._last
+
+    def export_history(self) -> dict[str, list[float]]:
+        """Chronological bounded history as Python lists."""
+        if not self._track or self._count == 0 or self._ring is None:
+            return {k: [] for k in _KEYS}
+        start = (self._next - self._count) % self._capacity
+        if start + self._count <= self._capacity:
+            window = self._ring[:, start:start + self._count]
+        else:
+            window = torch.cat((self._ring[:, start:], self._ring[:, :self._count - (self._capacity - start)]), dim=1)
+        rows = window.cpu().tolist()
+        return dict(zip(_KEYS, rows, strict=True))
+
+    def _sync_pending(self) -> LoggedLoss | None:
+        if self._pending is None:
+            return None
+        step, triple = self._pending
+        s, c, t = self._to_floats(triple)
+        self._last = LoggedLoss(step=step, style_loss=s, content_loss=c, total_loss=t)
+        return self._last
+
+    def _to_floats(self, triple: torch.Tensor) -> tuple[float, float, float]:
+        s, c, t = triple.tolist()          # the only host synchronisation
+        return float(s), float(c), float(t)

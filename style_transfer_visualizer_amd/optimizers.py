@@ -1,0 +1,116 @@
+"""Device-resident optimizers with the ``torch.optim`` ``step(closure)`` protocol.
+
+``HipLBFGS`` replaces ``torch.optim.LBFGS`` as constructed by the reference
+(core_model.py:344-349, optimization.py:212-217) for its default
+``max_iter = max_eval = 1`` configuration: same state machine, but every scalar
+and branch stays on the GPU (``stv_lbfgs_step``), so ``step`` never syncs.
+``HipAdam`` is the injected-Adam counterpart (reference tests/test_optimization.py:178).
+"""
+from __future__ import annotations
+
+from collections.abc import Callable
+
+import torch
+
+from . import ops
+
+
+def _single_param(params) -> torch.Tensor:
+    plist = list(params)
+    if len(plist) != 1 or not isinstance(plist[0], torch.Tensor):
+        msg = "HIP optimizers take exactly one tensor (the image being optimised)"
+        raise ValueError(msg)
+    p = plist[0]
+    if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+        msg = "HIP optimizers need a contiguous float32 GPU tensor (no CPU fallback on this path)"
+        raise RuntimeError(msg)
+    return p
+
+
+class HipLBFGS(torch.optim.Optimizer):
+    """L-BFGS without line search, one iteration per ``step`` (torch semantics)."""
+
+    def __init__(self, params, lr: float = 1.0, max_iter: int = 1, max_eval: int | None = None,
+                 tolerance_grad: float = 1e-7, tolerance_change: float = 1e-9,
+                 history_size: int = 100) -> None:
+        if lr < 0.0:
+            msg = f"Invalid learning rate: {lr}"
+            raise ValueError(msg)
+        if max_iter != 1:
+            msg = "HipLBFGS implements max_iter=1 (the reference default); use make_lbfgs for other settings"
+            raise ValueError(msg)
+        if not 1 <= history_size <= 128:
+            msg = "history_size must be in [1, 128]"
+            raise ValueError(msg)
+        if max_eval is None:
+            max_eval = max_iter * 5 // 4
+        p = _single_param(params)
+        defaults = dict(lr=lr, max_iter=max_iter, max_eval=max_eval, tolerance_grad=tolerance_grad,
+                        tolerance_change=tolerance_change, history_size=history_size, line_search_fn=None)
+        super().__init__([p], defaults)
+        self._p = p
+        self._dev_state, self._work = ops.lbfgs_alloc(p.numel(), history_size, p.device)
+        self._steps = 0
+
+    @torch.no_grad()
+    def step(self, closure: Callable[[], torch.Tensor]) -> torch.Tensor:  # type: ignore[override]
+        with torch.enable_grad():
+            loss = closure()
+        g = self.param_groups[0]
+        grad = self._p.grad
+        if grad is None:
+            grad = torch.zeros_like(self._p)
+        if not grad.is_contiguous():
+            grad = grad.contiguous()
+        ops.lbfgs_step(self._p, grad, self._dev_state, self._work, g["history_size"],
+                       min(self._steps, g["history_size"]), float(g["lr"]), g["tolerance_grad"],
+                       g["tolerance_change"])
+        self._steps += 1
+        return loss
+
+    def device_state(self) -> dict:
+        """Debug/test view of the device state block (this call synchronises)."""
+        raw = self._dev_state.cpu()
+        ints, flts = raw.view(torch.int32), raw.view(torch.float32)
+        return {"n_iter": int(ints[0]), "hist_len": int(ints[1]), "head": int(ints[2]), "skip": int(ints[3]),
+                "no_update": int(ints[4]), "steps_seen": int(ints[5]), "t": float(flts[6]),
+                "H_diag": float(flts[7]), "gtd": float(flts[8]), "gmax": float(flts[9])}
+
+
+class HipAdam(torch.optim.Optimizer):
+    """Adam (no amsgrad / weight decay) as one fused pass per step."""
+
+    def __init__(self, params, lr: float = 1e-3, betas: tuple[float, float] = (0.9, 0.999),
+                 eps: float = 1e-8) -> None:
+        p = _single_param(params)
+        super().__init__([p], dict(lr=lr, betas=betas, eps=eps))
+        self._p = p
+        self._m = torch.zeros_like(p, requires_grad=False)
+        self._v = torch.zeros_like(p, requires_grad=False)
+        self._t = 0
+
+    @torch.no_grad()
+    def step(self, closure: Callable[[], torch.Tensor] | None = None):  # type: ignore[override]
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        if self._p.grad is None:
+            return loss
+        g = self.param_groups[0]
+        self._t += 1
+        ops.adam_step(self._p, self._p.grad.contiguous(), self._m, self._v, self._t, lr=g["lr"],
+                      betas=g["betas"], eps=g["eps"])
+        return loss
+
+
+def make_lbfgs(input_img: torch.Tensor, lr: float, max_iter: int, max_eval: int) -> torch.optim.Optimizer:
+    """L-BFGS for the image: device-resident when it can be, ``torch.optim.LBFGS`` otherwise.
+
+    The device-resident form covers the reference default (one iteration per
+    step on a float32 GPU image).  Other settings run torch's optimizer on the
+    same GPU tensors; the closure (all the FLOPs) is the HIP path either way.
+    """
+    if max_iter == 1 and input_img.is_cuda and input_img.dtype == torch.float32:
+        return HipLBFGS([input_img], lr=lr, max_iter=max_iter, max_eval=max_eval)
+    return torch.optim.LBFGS([input_img], lr=lr, max_iter=max_iter, max_eval=max_eval)

@@ -1,0 +1,309 @@
+"""Lower a sliced VGG feature stack + loss taps to ``stv_op_t`` command buffers.
+
+This is the host half of the hot path: it runs once per (model, image size),
+allocates every activation / gradient / workspace buffer through PyTorch, and
+emits flat op arrays that ``libstv_hip.so`` executes each optimisation step
+(``stv_program_run``).  It restates, as a schedule, what autograd does for the
+reference's ``StyleContentModel.forward`` + ``loss.backward()``
+(/root/reference/src/style_transfer_visualizer/core_model.py:297-328,
+optimization.py:292-313):
+
+* conv -> ReLU pairs are fused (ReLU in the producer's epilogue) unless the
+  conv output itself is tapped; then the consumer applies ReLU while staging;
+* every gradient w.r.t. a stored activation is written exactly once by its
+  consumer (with the ReLU mask fused in the epilogue) and tap gradients
+  (Gram product, content difference) accumulate on top;
+* Gram backward is ``dF = F . S`` with the symmetric seed ``S`` produced by
+  ``stv_gram_finish``; it runs as a 1x1 conv on the matrix cores.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass, field
+
+import torch
+from torch import nn
+
+from . import _lib, ops
+from ._lib import (ACCUM, MASK, OP_CONTENT_GRAD, OP_CONTENT_LOSS, OP_CONV, OP_CONV_FIRST_DGRAD,
+                   OP_CONV_FIRST_FWD, OP_GRAM_FINISH, OP_GRAM_PARTIAL, OP_LOSS_COMBINE, OP_POOL_BWD,
+                   OP_POOL_FWD, OP_RELU_BWD, OP_RELU_FWD, RELU_IN, RELU_OUT, StvOp)
+
+GRAM_CLAMP_MAX = 5e5  # reference constants.py:15
+
+
+@dataclass
+class Buf:
+    """One materialised activation (NHWC) and, for the backward pass, its gradient."""
+
+    H: int
+    W: int
+    C: int
+    act: torch.Tensor
+    relu_fused: bool = False       # stored value is relu(z)
+    taps: list = field(default_factory=list)
+    grad: torch.Tensor | None = None
+
+
+@dataclass
+class Node:
+    kind: str                      # conv_first | conv | pool | relu
+    src: Buf | None
+    dst: Buf
+    relu_in: bool = False
+    layer: int = -1
+    wf: torch.Tensor | None = None
+    wb: torch.Tensor | None = None
+    bias: torch.Tensor | None = None
+    cin: int = 0
+
+
+@dataclass
+class Tap:
+    kind: str                      # style | content
+    order: int                     # index inside its kind (block order)
+    buf: Buf
+    target: torch.Tensor | None = None
+    # style
+    partials: torch.Tensor | None = None
+    sgrad: torch.Tensor | None = None
+    parts_off: int = 0
+    parts_cnt: int = 0
+
+
+def _check_layer(layer: nn.Module, idx: int) -> str:
+    if isinstance(layer, nn.Conv2d):
+        ok = (layer.kernel_size == (3, 3) and layer.stride == (1, 1) and layer.padding == (1, 1)
+              and layer.dilation == (1, 1) and layer.groups == 1 and layer.padding_mode == "zeros")
+        if not ok:
+            msg = f"layer {idx}: only Conv2d(k=3, stride=1, padding=1) has a HIP kernel"
+            raise RuntimeError(msg)
+        return "conv"
+    if isinstance(layer, nn.ReLU):
+        return "relu"
+    if isinstance(layer, nn.MaxPool2d):
+        ks = layer.kernel_size if isinstance(layer.kernel_size, tuple) else (layer.kernel_size,) * 2
+        stv = layer.stride if isinstance(layer.stride, tuple) else (layer.stride,) * 2
+        pad = layer.padding if isinstance(layer.padding, tuple) else (layer.padding,) * 2
+        if ks != (2, 2) or stv != (2, 2) or pad != (0, 0) or layer.ceil_mode:
+            msg = f"layer {idx}: only MaxPool2d(2, 2) has a HIP kernel"
+            raise RuntimeError(msg)
+        return "pool"
+    msg = f"layer {idx}: {type(layer).__name__} has no HIP kernel on this path"
+    raise RuntimeError(msg)
+
+
+class Schedule:
+    """Buffers + forward/backward op lists for one image size."""
+
+    def __init__(self, layers: list[nn.Module], style_at: list[int], content_at: list[int],
+                 H: int, W: int, dtype: torch.dtype, device: torch.device, *, with_grad: bool) -> None:
+        self.H, self.W, self.dtype, self.device = H, W, dtype, device
+        self.nodes: list[Node] = []
+        self.style_taps: list[Tap] = []
+        self.content_taps: list[Tap] = []
+        self.with_grad = with_grad
+        self._keep: list = []      # tensors referenced by raw pointer from op arrays
+        self._lower_forward(layers, style_at, content_at)
+
+    # ------------------------------------------------------------------ forward walk
+    def _new_buf(self, H: int, W: int, C: int) -> Buf:
+        act = torch.empty(H, W, C, device=self.device, dtype=self.dtype)
+        return Buf(H, W, C, act)
+
+    def _lower_forward(self, layers: list[nn.Module], style_at: list[int], content_at: list[int]) -> None:
+        tapped = set(style_at) | set(content_at)
+        last = max(tapped)
+        kinds = [_check_layer(layer, i) for i, layer in enumerate(layers[:last + 1])]
+        cur: Buf | None = None           # None = the NCHW fp32 image
+        pending_relu = False
+        H, W = self.H, self.W
+        i = 0
+        while i <= last:
+            kind = kinds[i]
+            out_idx = i
+            if kind == "conv":
+                conv: nn.Conv2d = layers[i]
+                w = conv.weight.detach().to(self.device, torch.float32)
+                bias = (conv.bias.detach().to(self.device, torch.float32).contiguous()
+                        if conv.bias is not None else None)
+                cout, cin = w.shape[:2]
+                dst = self._new_buf(H, W, cout)
+                if cur is None:
+                    if pending_relu:
+                        msg = "a ReLU in front of the first convolution is not supported"
+                        raise RuntimeError(msg)
+                    node = Node("conv_first", None, dst, layer=i, wf=ops.pack_weights_fwd(w), bias=bias, cin=cin)
+                else:
+                    node = Node("conv", cur, dst, relu_in=pending_relu, layer=i,
+                                wf=ops.pack_weights_fwd(w).to(self.dtype),
+                                wb=ops.pack_weights_bwd(w).to(self.dtype) if self.with_grad else None,
+                                bias=bias, cin=cin)
+                pending_relu = False
+                if i + 1 <= last and kinds[i + 1] == "relu" and i not in tapped:
+                    dst.relu_fused = True      # ReLU runs in this conv's epilogue
+                    out_idx = i + 1
+                self.nodes.append(node)
+                cur = dst
+            elif kind == "relu":
+                if cur is None:
+                    msg = "ReLU directly on the input image is not supported"
+                    raise RuntimeError(msg)
+                if i in tapped:
+                    dst = self._new_buf(cur.H, cur.W, cur.C)
+                    self.nodes.append(Node("relu", cur, dst, layer=i))
+                    cur = dst
+                    pending_relu = False
+                else:
+                    pending_relu = True        # applied by the consumer while staging
+            else:  # pool
+                if cur is None:
+                    msg = "MaxPool directly on the input image is not supported"
+                    raise RuntimeError(msg)
+                H, W = H // 2, W // 2
+                if H < 1 or W < 1:
+                    msg = "image too small for this many pooling layers"
+                    raise RuntimeError(msg)
+                dst = self._new_buf(H, W, cur.C)
+                self.nodes.append(Node("pool", cur, dst, layer=i))
+                cur = dst
+                if pending_relu and i in tapped:   # relu(pool(z)) must exist as data
+                    r = self._new_buf(H, W, cur.C)
+                    self.nodes.append(Node("relu", cur, r, layer=i))
+                    cur = r
+                    pending_relu = False
+            for idx in range(i, out_idx + 1):
+                if idx in style_at:
+                    assert cur is not None
+                    tap = Tap("style", len(self.style_taps), cur)
+                    cur.taps.append(tap)
+                    self.style_taps.append(tap)
+                if idx in content_at:
+                    assert cur is not None
+                    tap = Tap("content", len(self.content_taps), cur)
+                    cur.taps.append(tap)
+                    self.content_taps.append(tap)
+            i = out_idx + 1
+
+    # ------------------------------------------------------------------ op emission
+    def _op(self, **kw) -> StvOp:
+        op = StvOp()
+        op.dtype = ops.dtype_code(self.dtype)
+        for k, v in kw.items():
+            if isinstance(v, torch.Tensor):
+                self._keep.append(v)
+                v = v.data_ptr()
+            setattr(op, k, v)
+        return op
+
+    def forward_ops(self, x: torch.Tensor) -> list[StvOp]:
+        out = []
+        for nd in self.nodes:
+            d = nd.dst
+            if nd.kind == "conv_first":
+                out.append(self._op(op=OP_CONV_FIRST_FWD, p0=x, p1=nd.wf, p2=nd.bias, q0=d.act,
+                                    H=d.H, W=d.W, cin=nd.cin, cout=d.C))
+            elif nd.kind == "conv":
+                flags = (RELU_IN if nd.relu_in else 0) | (RELU_OUT if d.relu_fused else 0)
+                out.append(self._op(op=OP_CONV, p0=nd.src.act, p1=nd.wf, p2=nd.bias, q0=d.act, H=d.H, W=d.W,
+                                    cin=nd.cin, cout=d.C, taps=9, flags=flags))
+            elif nd.kind == "pool":
+                out.append(self._op(op=OP_POOL_FWD, p0=nd.src.act, q0=d.act, H=nd.src.H, W=nd.src.W, cin=d.C))
+            else:
+                out.append(self._op(op=OP_RELU_FWD, p0=nd.src.act, q0=d.act, n=d.act.numel()))
+        return out
+
+    def gram_ops(self, tap: Tap, *, gram_out: torch.Tensor | None, target: torch.Tensor | None,
+                 loss_part: torch.Tensor | None, sgrad: torch.Tensor | None, coef: float,
+                 coef_dev: torch.Tensor | None, partial: bool = True) -> list[StvOp]:
+        b = tap.buf
+        n = b.H * b.W
+        if tap.partials is None:
+            tap.partials = torch.empty(ops.gram_ksplit(n, b.C), b.C, b.C, device=self.device, dtype=torch.float32)
+        out = []
+        if partial:
+            out.append(self._op(op=OP_GRAM_PARTIAL, p0=b.act, q0=tap.partials, n=n, cin=b.C))
+        out.append(self._op(op=OP_GRAM_FINISH, p0=tap.partials, p1=target, p2=coef_dev, q0=gram_out, q1=loss_part,
+                            q2=sgrad, n=n, cin=b.C, f0=GRAM_CLAMP_MAX, f1=float(b.C * n), f2=coef))
+        return out
+
+    def alloc_grads(self) -> None:
+        for nd in self.nodes:
+            if nd.dst.grad is None:
+                nd.dst.grad = torch.empty_like(nd.dst.act)
+
+    def backward_ops(self, x_grad: torch.Tensor, *, style_coef: float, content_coef: float,
+                     coef_dev: torch.Tensor | None) -> list[StvOp]:
+        """Reverse schedule.  ``coef_dev`` (optional fp32 device vector, style terms
+        first) holds upstream d(total)/d(loss_k) for the autograd path."""
+        self.alloc_grads()
+        out: list[StvOp] = []
+        written: set[int] = set()
+
+        def acc_flag(buf: Buf) -> int:
+            return ACCUM if id(buf) in written else 0
+
+        n_style = len(self.style_taps)
+        for nd in reversed(self.nodes):
+            d = nd.dst
+            for tap in d.taps:
+                if tap.kind == "style":
+                    out.append(self._op(op=OP_CONV, p0=d.act, p1=tap.sgrad, q0=d.grad, H=d.H, W=d.W,
+                                        cin=d.C, cout=d.C, taps=1, flags=acc_flag(d)))
+                else:
+                    cd = coef_dev[n_style + tap.order:] if coef_dev is not None else None
+                    out.append(self._op(op=OP_CONTENT_GRAD, p0=d.act, p1=tap.target, p2=cd, q0=d.grad,
+                                        n=d.act.numel(), f0=content_coef, flags=acc_flag(d)))
+                written.add(id(d))
+            if id(d) not in written:
+                msg = "internal: activation without any gradient contribution"
+                raise RuntimeError(msg)
+            if d.relu_fused and d.taps:
+                # taps see relu(z): mask the summed gradient once, in place
+                out.append(self._op(op=OP_RELU_BWD, p0=d.act, p1=d.grad, q0=d.grad, n=d.act.numel()))
+            s = nd.src
+            if nd.kind == "conv_first":
+                out.append(self._op(op=OP_CONV_FIRST_DGRAD, p0=d.grad, p1=nd.wf, q0=x_grad, H=d.H, W=d.W,
+                                    cin=nd.cin, cout=d.C))
+                continue
+            mask_src = nd.relu_in or (s.relu_fused and not s.taps)
+            if nd.kind == "conv":
+                flags = (MASK if mask_src else 0) | acc_flag(s)
+                out.append(self._op(op=OP_CONV, p0=d.grad, p1=nd.wb, p3=s.act if mask_src else None, q0=s.grad,
+                                    H=s.H, W=s.W, cin=d.C, cout=s.C, taps=9, flags=flags))
+            elif nd.kind == "pool":
+                flags = (MASK if (s.relu_fused and not s.taps) else 0) | acc_flag(s)
+                out.append(self._op(op=OP_POOL_BWD, p0=s.act, p1=d.grad, q0=s.grad, H=s.H, W=s.W, cin=s.C,
+                                    flags=flags))
+            else:  # materialised relu
+                out.append(self._op(op=OP_RELU_BWD, p0=s.act, p1=d.grad, q0=s.grad, n=s.act.numel(),
+                                    flags=acc_flag(s)))
+            written.add(id(s))
+        _ = style_coef
+        return out
+
+
+class Program:
+    """Owns a ``stv_program`` handle (host object inside libstv_hip.so)."""
+
+    def __init__(self, op_list: list[StvOp], keep: list) -> None:
+        self._keep = list(keep)
+        arr = (StvOp * len(op_list))(*op_list)
+        handle = ctypes.c_void_p()
+        lib = _lib.load()
+        _lib.check(lib.stv_program_create(arr, len(op_list), ctypes.byref(handle)), "stv_program_create")
+        self._handle = handle
+        self.n_ops = len(op_list)
+
+    def run(self, use_graph: bool = False) -> None:
+        lib = _lib.load()
+        _lib.check(lib.stv_program_run(self._handle, 1 if use_graph else 0,
+                                       torch.cuda.current_stream().cuda_stream), "stv_program_run")
+
+    def __del__(self) -> None:
+        try:
+            if self._handle:
+                _lib.load().stv_program_destroy(self._handle)
+                self._handle = None
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass

@@ -1,0 +1,169 @@
+"""End-to-end parity of the HIP path on MI355X against the golden vectors captured
+from the unmodified reference (tests/golden, produced by oracle/make_golden.py)
+and against the CPU oracle on the same seeded inputs.
+
+north_star tolerance: 1e-4 relative per pixel (fp32 parity mode), bit-exact step
+indices / history lengths / logging cadence.
+"""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import core_model_ref as ocm
+from style_transfer_visualizer_amd import config as stv_config
+from style_transfer_visualizer_amd import core_model, optimization, optimizers, synthetic
+from tests.conftest import GoldenCase
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda")
+
+
+class _Bar:
+    def update(self, n=1):
+        return None
+
+    def set_postfix(self, *a, **k):
+        return None
+
+    def close(self):
+        return None
+
+
+def _build(case: GoldenCase, monkeypatch, precision="fp32"):
+    m = case.meta
+    weights = case.weights()
+    monkeypatch.setattr(core_model, "initialize_vgg",
+                        lambda: core_model.build_vgg_features(weights, case.cfg).eval())
+    cfg = stv_config.StyleTransferConfig.model_validate({})
+    oc = cfg.optimization
+    oc.steps, oc.style_w, oc.content_w = m["steps"], m["style_w"], m["content_w"]
+    oc.init_method = m["init_method"]
+    oc.style_layers, oc.content_layers = list(m["style_layers"]), list(m["content_layers"])
+    oc.normalize = m["normalize"]
+    cfg.hardware.precision = precision
+    cfg.output.log_every = 2
+    cfg.video.create_video = False
+    content, style = case.images()
+    model, input_img, opt = core_model.prepare_model_and_input(content.to(DEV), style.to(DEV), DEV, oc,
+                                                               precision=precision)
+    with torch.no_grad():
+        input_img.copy_(case.tensor("x0").to(DEV))     # identical start (covers init_method=random)
+    return cfg, model, input_img, opt
+
+
+def test_targets_and_first_step_match_reference(golden_case: GoldenCase, monkeypatch):
+    case = golden_case
+    m = case.meta
+    cfg, model, x, _ = _build(case, monkeypatch)
+    assert len(model.vgg_blocks) == m["block_count"]
+    assert model.style_ids == m["style_ids"] and model.content_ids == m["content_ids"]
+    for i, t in enumerate(model.style_targets):
+        got = t.cpu().numpy()
+        if f"style_target_{i}" in case.arrays:
+            ref = case.arrays[f"style_target_{i}"]
+        else:
+            got, ref = got[::16, ::16], case.arrays[f"style_target_{i}_sub16"]
+        np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-5 * np.abs(ref).max())
+    for i, t in enumerate(model.content_targets):
+        assert float(t.double().abs().sum().cpu()) == pytest.approx(
+            float(case.arrays[f"content_target_{i}_abs_sum"]), rel=1e-4)
+
+    g_ref = case.arrays["grad_step1"]
+    gscale = np.abs(g_ref).max()
+    # fused path
+    s, c, tot = model.loss_and_grad(x, m["style_w"], m["content_w"])
+    assert float(s) == pytest.approx(case.arrays["style_loss"][0], rel=2e-4)
+    assert float(c) == pytest.approx(case.arrays["content_loss"][0], rel=2e-4)
+    assert float(tot) == pytest.approx(case.arrays["total_loss"][0], rel=2e-4)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g_ref, rtol=0, atol=2e-4 * gscale)
+    fused_grad = x.grad.clone()
+    # autograd path: model(x) -> lists of 0-d tensors -> loss.backward()
+    x.grad = None
+    s_losses, c_losses = model(x)
+    assert len(s_losses) == len(m["style_layers"]) and len(c_losses) == len(m["content_layers"])
+    assert all(t.dim() == 0 for t in s_losses + c_losses)
+    loss = m["style_w"] * torch.stack(s_losses).sum() + m["content_w"] * torch.stack(c_losses).sum()
+    loss.backward()
+    assert float(loss) == pytest.approx(case.arrays["total_loss"][0], rel=2e-4)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g_ref, rtol=0, atol=2e-4 * gscale)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), fused_grad.cpu().numpy(), rtol=0, atol=1e-5 * gscale)
+
+
+def test_trajectory_matches_reference(golden_case: GoldenCase, monkeypatch):
+    case = golden_case
+    m = case.meta
+    cfg, model, x, opt = _build(case, monkeypatch)
+    if m["optimizer"] == "adam":
+        opt = optimizers.HipAdam([x], lr=m["adam_lr"])
+    seen = []
+    runner = optimization.OptimizationRunner(
+        model, x, cfg, optimizer=opt, progress_bar=_Bar(),
+        callbacks=optimization.OptimizationCallbacks(on_step_end=lambda mt: seen.append((mt.step, mt.has_values))))
+    out, history, _ = runner.run()
+    steps = m["steps"]
+    # integer bookkeeping: bit-exact
+    assert [s for s, _ in seen] == list(range(1, steps + 1))
+    assert [s for s, has in seen if has] == case.arrays["logged_steps"].tolist()
+    assert runner._closure_calls == int(case.arrays["closure_calls"])
+    assert len(history["total_loss"]) == steps
+    # losses per step and final image
+    np.testing.assert_allclose(history["total_loss"], case.arrays["total_loss"], rtol=1e-3)
+    np.testing.assert_allclose(history["style_loss"], case.arrays["style_loss"], rtol=1e-3)
+    np.testing.assert_allclose(history["content_loss"], case.arrays["content_loss"], rtol=1e-3)
+    xf = case.arrays["x_final"]
+    np.testing.assert_allclose(out.detach().cpu().numpy(), xf, rtol=0, atol=1e-4 * np.abs(xf).max())
+
+
+def test_bf16_storage_tracks_fp32(monkeypatch):
+    """bf16 activation storage (perf mode): losses within bf16 rounding of the fp32 reference."""
+    case = GoldenCase("vgg19_white_lbfgs")
+    m = case.meta
+    cfg, model, x, _ = _build(case, monkeypatch, precision="bf16")
+    s, c, tot = model.loss_and_grad(x, m["style_w"], m["content_w"])
+    assert float(tot) == pytest.approx(case.arrays["total_loss"][0], rel=5e-2)
+    g_ref = case.arrays["grad_step1"]
+    err = np.abs(x.grad.cpu().numpy() - g_ref).max() / np.abs(g_ref).max()
+    assert err < 0.1, f"bf16 gradient drifted {err:.3f} of scale"
+
+
+def test_oracle_agreement_at_larger_size(monkeypatch):
+    """Same seeded inputs through oracle (CPU) and HIP at 160x128 with the mini net."""
+    case = GoldenCase("mini_white_lbfgs")
+    weights = case.weights()
+    monkeypatch.setattr(core_model, "initialize_vgg",
+                        lambda: core_model.build_vgg_features(weights, case.cfg).eval())
+    content = synthetic.synthetic_image(4, 160, 128)
+    style = synthetic.synthetic_image(5, 96, 200)
+    S, C = case.meta["style_layers"], case.meta["content_layers"]
+    prog = ocm.vgg_program(weights, case.cfg)
+    oracle = ocm.OracleModel(prog, S, C)
+    oracle.set_targets(style, content)
+    x0 = synthetic.synthetic_image(6, 160, 128)
+    s_ref, c_ref, t_ref, g_ref = ocm.loss_and_grad(oracle, x0, 1e5, 1.0)
+    model = core_model.StyleContentModel(S, C).to(DEV)
+    model.set_targets(style.to(DEV), content.to(DEV))
+    x = x0.to(DEV).requires_grad_(True)
+    s, c, t = model.loss_and_grad(x, 1e5, 1.0)
+    assert float(t) == pytest.approx(float(t_ref), rel=2e-4)
+    assert float(s) == pytest.approx(float(s_ref), rel=2e-4)
+    assert float(c) == pytest.approx(float(c_ref), rel=2e-4)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g_ref.numpy(), rtol=0, atol=2e-4 * float(g_ref.abs().max()))
+
+
+def test_model_errors_match_reference_texts(monkeypatch):
+    case = GoldenCase("tiny_taps_lbfgs")
+    weights = case.weights()
+    monkeypatch.setattr(core_model, "initialize_vgg",
+                        lambda: core_model.build_vgg_features(weights, case.cfg).eval())
+    model = core_model.StyleContentModel([0], [1]).to(DEV)
+    x = torch.randn(1, 3, 16, 16, device=DEV)
+    model.content_targets = [x]
+    with pytest.raises(RuntimeError, match="style_targets must be set"):
+        model(x)
+    model.style_targets, model.content_targets = [x], None
+    with pytest.raises(RuntimeError, match="content_targets must be set"):
+        model(x)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        core_model.StyleContentModel([0], [1]).set_targets(x.cpu(), x.cpu())
