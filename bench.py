@@ -1,0 +1,289 @@
+#!/usr/bin/env python3
+"""Benchmark of the per-step optimisation hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one ``optimizer.step(closure)`` of the reference loop
+(optimization.py:175): VGG19 forward + Gram/content losses + backward to the
+image + L-BFGS update.  Workload at N=1: BASELINE.json configs[1] (single
+512x512 image, L-BFGS, VGG19 bf16 storage, --no-video); with --size 1024 it is
+configs[2].  For N>1 every rank optimises its own independent content/style
+pair (configs[3] pattern: no data-path collective; one RCCL all-gather of the
+final images after the timed region) -> weak scaling.
+
+Inputs are synthetic and resident in HBM before the timed region: U[0,1) RGB
+images from the counter-hash PRNG, ImageNet-normalised; VGG19-topology weights
+from the same PRNG (He-scaled) because the pretrained checkpoint cannot be
+fetched here.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+BF16_PEAK_TFLOPS = 2500.0     # dense MFMA peak, MI355X_MICROARCH.md
+FP32_PEAK_TFLOPS = 157.3
+HBM_PEAK_GBS = 8000.0
+
+
+class _Bar:
+    def update(self, n=1):
+        return None
+
+    def set_postfix(self, *a, **k):
+        return None
+
+    def close(self):
+        return None
+
+
+def conv_flops(meta) -> float:
+    op, H, W, cin, cout, taps, _n = meta
+    return 2.0 * max(taps, 1) * cin * cout * H * W
+
+
+def kernel_group(meta, OP) -> str | None:
+    op, H, W, cin, cout, taps, _n = meta
+    if op == OP["CONV"]:
+        th = 4 if H <= 4 else 8
+        bn = 64 if cout <= 64 else 128
+        return f"conv_igemm<T,TH={th},BN={bn},taps={taps}>"
+    names = {OP["CONV_FIRST_FWD"]: "conv_first_fwd", OP["CONV_FIRST_DGRAD"]: "conv_first_dgrad",
+             OP["POOL_FWD"]: "maxpool_fwd", OP["POOL_BWD"]: "maxpool_bwd", OP["GRAM_PARTIAL"]: "gram_partial",
+             OP["GRAM_FINISH"]: "gram_finish", OP["CONTENT_LOSS"]: "content_loss",
+             OP["CONTENT_GRAD"]: "content_grad", OP["LOSS_COMBINE"]: "loss_combine",
+             OP["RELU_FWD"]: "relu_fwd", OP["RELU_BWD"]: "relu_bwd"}
+    return names.get(op)
+
+
+def forward_bytes(sched, dtype_bytes: int) -> float:
+    """SURVEY.md §8(d) byte model for forward+Gram: every tensor read once, written once."""
+    total = 0.0
+    for nd in sched.nodes:
+        out_b = nd.dst.act.numel() * dtype_bytes
+        if nd.kind == "conv_first":
+            total += nd.dst.H * nd.dst.W * nd.cin * 4 + out_b + nd.wf.numel() * 4
+        elif nd.kind == "conv":
+            total += nd.src.act.numel() * dtype_bytes + out_b + nd.wf.numel() * 4   # weights counted fp32 as §8(d)
+        else:
+            total += nd.src.act.numel() * dtype_bytes + out_b
+    for tap in sched.style_taps:
+        total += tap.buf.act.numel() * dtype_bytes
+    for tap in sched.content_taps:
+        total += 2 * tap.buf.act.numel() * dtype_bytes
+    return total
+
+
+def run_gpu(args, rank: int, world: int, device: torch.device, size: int, steps: int, warmup: int):
+    import torch.distributed as dist
+
+    from style_transfer_visualizer_amd import _lib, config as stv_config
+    from style_transfer_visualizer_amd import core_model, optimization, synthetic
+
+    os.environ.setdefault("STV_SYNTHETIC_WEIGHTS", "0")
+    cfg = stv_config.StyleTransferConfig.model_validate({})
+    oc = cfg.optimization
+    oc.steps = warmup + steps
+    oc.init_method = "random"
+    cfg.hardware.precision = args.precision
+    cfg.video.create_video = False
+    cfg.video.final_only = True
+    cfg.output.log_every = 10
+    torch.manual_seed(oc.seed + rank)
+    torch.cuda.manual_seed_all(oc.seed + rank)
+    content = synthetic.synthetic_image(2 * rank, size, size).to(device)
+    style = synthetic.synthetic_image(2 * rank + 1, size, size).to(device)
+    model, x, opt = core_model.prepare_model_and_input(content, style, device, oc, precision=args.precision)
+    torch.cuda.synchronize(device)
+
+    marks = {}
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        return time.perf_counter()
+
+    def on_end(metrics):
+        if metrics.step == warmup:
+            marks["t0"] = fence()
+        elif metrics.step == warmup + steps:
+            marks["t1"] = fence()
+
+    if warmup == 0:
+        marks["t0"] = fence()
+    runner = optimization.OptimizationRunner(
+        model, x, cfg, optimizer=opt, progress_bar=_Bar(),
+        callbacks=optimization.OptimizationCallbacks(on_step_end=on_end))
+    out, _history, _ = runner.run()
+    elapsed = marks["t1"] - marks["t0"]
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        # the only collective of the job: gather the independent results (RCCL over xGMI)
+        gathered = [torch.empty_like(out.detach()) for _ in range(world)]
+        dist.all_gather(gathered, out.detach().contiguous())
+        assert len(gathered) == world
+
+    info = {"elapsed": elapsed}
+    st = opt.device_state() if hasattr(opt, "device_state") else {}
+    info["lbfgs"] = {k: st.get(k) for k in ("n_iter", "hist_len", "skip", "no_update")}
+    if rank == 0:
+        # per-op device time of the fused step (HIP events on the launch stream), 3 passes
+        eng = next(iter(model._engines.values()))
+        prog = next(p for k, p in eng._programs.items() if k[0] == "fused")
+        OP = {n[3:]: getattr(_lib, n) for n in dir(_lib) if n.startswith("OP_")}
+        side = torch.cuda.Stream(device=device)
+        with torch.cuda.stream(side):
+            prog.profile()
+            passes = [prog.profile() for _ in range(3)]
+        ms = [sum(p[i] for p in passes) / len(passes) for i in range(prog.n_ops)]
+        groups: dict = {}
+        for meta, t in zip(prog.op_meta, ms, strict=True):
+            g = kernel_group(meta, OP)
+            e = groups.setdefault(g, {"ms": 0.0, "flops": 0.0, "launches": 0})
+            e["ms"] += t
+            e["launches"] += 1
+            if meta[0] == OP["CONV"]:
+                e["flops"] += conv_flops(meta)
+        dom_name, dom = max(groups.items(), key=lambda kv: kv[1]["ms"])
+        peak = BF16_PEAK_TFLOPS if args.precision == "bf16" else FP32_PEAK_TFLOPS
+        achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+        info["roofline"] = {
+            "bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": peak,
+            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+            "launches_per_step": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 5),
+            "flop_per_launch": dom["flops"] / dom["launches"],
+        }
+        n_fwd = len(eng.sched.nodes)
+        fwd_gram_ms = sum(t for meta, t in zip(prog.op_meta[:n_fwd], ms[:n_fwd], strict=True))
+        fwd_gram_ms += sum(t for meta, t in zip(prog.op_meta[n_fwd:], ms[n_fwd:], strict=True)
+                           if meta[0] in (OP["GRAM_PARTIAL"], OP["GRAM_FINISH"]))
+        dtype_bytes = 2 if args.precision == "bf16" else 4
+        b_fwd = forward_bytes(eng.sched, dtype_bytes)
+        total_flops = sum(e["flops"] for e in groups.values())
+        step_ms = sum(ms)
+        info["breakdown_ms"] = {k: round(v["ms"], 4) for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])}
+        info["fwd_gram"] = {"ms": round(fwd_gram_ms, 4), "algorithmic_MB": round(b_fwd / 1e6, 1),
+                            "hbm_frac": round(b_fwd / (fwd_gram_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        info["closure"] = {"ms": round(step_ms, 4), "conv_gflop": round(total_flops / 1e9, 1),
+                           "mfma_frac": round(total_flops / (step_ms * 1e-3) / 1e12 / peak, 4)}
+    return info
+
+
+def cpu_baseline(size: int, threads: int) -> dict:
+    """Reference algorithm on the host cores: the torch-CPU oracle (fp32), bounded sample."""
+    from oracle import core_model_ref as ocm
+    from oracle import optim_ref
+    from style_transfer_visualizer_amd import synthetic
+
+    torch.set_num_threads(threads)
+    weights = synthetic.synthetic_conv_weights(0)
+    model = ocm.OracleModel(ocm.vgg_program(weights, synthetic.VGG19_CFG), (0, 5, 10, 19, 28), (21,))
+    content = synthetic.synthetic_image(0, size, size)
+    style = synthetic.synthetic_image(1, size, size)
+    model.set_targets(style, content)
+    x = torch.randn(content.shape, generator=torch.Generator().manual_seed(0))
+    opt = optim_ref.LbfgsRef(x.view(-1), lr=1.0)
+
+    def closure():
+        _s, _c, t, g = ocm.loss_and_grad(model, x, 1e5, 1.0)
+        return t, g
+    warm, timed = 2, (6 if size <= 512 else 2)
+    for _ in range(warm):
+        opt.step(closure)
+    t0 = time.perf_counter()
+    for _ in range(timed):
+        opt.step(closure)
+    dt = time.perf_counter() - t0
+    return {"value": round(timed / dt, 4), "unit": "steps/s", "cores": threads, "kind": "port",
+            "sample": f"{size}x{size} VGG19 fp32, torch-CPU oracle, {warm} warm-up + {timed} timed L-BFGS steps"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the additional 1024x1024 measurement")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        print(json.dumps({"error": "no GPU: the HIP hot path has no CPU fallback"}))
+        sys.exit(2)
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    info = run_gpu(args, rank, world, device, args.size, args.steps, args.warmup)
+    extra = None
+    if not args.no_extra and args.size == 512 and world == 1:
+        k2, w2 = max(10, args.steps // 4), max(5, min(args.warmup, 100))
+        e = run_gpu(args, rank, world, device, 1024, k2, w2)
+        extra = {"workload": "single 1024x1024 image (BASELINE configs[2])", "steps": k2, "warmup": w2,
+                 "value": round(k2 / e["elapsed"], 3), "ms_per_step": round(1e3 * e["elapsed"] / k2, 4),
+                 "roofline": e.get("roofline"), "fwd_gram": e.get("fwd_gram"), "closure": e.get("closure"),
+                 "breakdown_ms": e.get("breakdown_ms"), "lbfgs": e.get("lbfgs")}
+
+    if rank == 0:
+        total_steps = args.steps * world
+        line = {
+            "metric": "optimization steps/sec at 512² and 1024², 1/2/4/8 MI355X",
+            "value": round(total_steps / info["elapsed"], 3),
+            "unit": "steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * info["elapsed"] / args.steps, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16" if args.precision == "bf16" else "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": (f"single {args.size}x{args.size} image per GPU, L-BFGS (max_iter=1, history 100), "
+                             f"VGG19 {args.precision} storage / fp32 accumulate, fp32 Gram, --no-video "
+                             "(BASELINE.json configs[1]); weights: synthetic He-scaled"),
+                "size": args.size, "images": world, "init_method": "random",
+                "style_w": 1e5, "content_w": 1.0, "parallelism": f"replicas x{world} (independent images)",
+            },
+            "roofline": info.get("roofline"),
+            "fwd_gram": info.get("fwd_gram"),
+            "closure": info.get("closure"),
+            "breakdown_ms": info.get("breakdown_ms"),
+            "lbfgs": info.get("lbfgs"),
+        }
+        if extra is not None:
+            line["extra_1024"] = extra
+        if world == 1 and not args.no_cpu_baseline:
+            threads = max(1, min(os.cpu_count() or 1, 16))
+            line["cpu_baseline"] = cpu_baseline(args.size, threads)
+        print(json.dumps(line))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -161,6 +161,10 @@ typedef struct stv_program stv_program;  /* host object */
 int stv_program_create(const stv_op_t* ops, int n_ops, stv_program** out);
 /* use_graph != 0: capture on first run, replay afterwards. */
 int stv_program_run(stv_program* prog, int use_graph, void* stream);
+/* Measurement helper: eager run with a hipEvent pair around every op (recorded on
+ * `stream`); ms_out[i] = device milliseconds of op i.  Synchronises. */
+int stv_program_profile(stv_program* prog, void* stream, float* ms_out, int n_out);
+int stv_program_op_count(const stv_program* prog);
 void stv_program_destroy(stv_program* prog);
 
 #ifdef __cplusplus

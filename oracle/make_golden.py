@@ -22,7 +22,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 sys.path.insert(0, ROOT)
 
-from oracle import ref_harness  # noqa: E402
+from oracle import core_model_ref as ocm  # noqa: E402
+from oracle import optim_ref, ref_harness  # noqa: E402
 from style_transfer_visualizer_amd import synthetic  # noqa: E402
 
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
@@ -54,6 +55,38 @@ def _weights(cfg, seed, gain_first=1.0, bias_scale=0.0):
             b = synthetic.synthetic_bias(seed, li, w.shape[0], bias_scale)
         out.append((w, b))
     return out
+
+
+def trajectory_sensitivity(weights, cfg, content, style, x0, *, style_layers, content_layers, style_w,
+                           content_w, steps, optimizer, adam_lr, eps=3e-7):
+    """Conditioning of the fixture's trajectory, measured on the (pinned) oracle.
+
+    The gradient of every step is perturbed at the level of fp32 rounding
+    (eps = 3e-7, about 2 ulp: what a different but equally valid summation order
+    produces), once as a per-step global factor (1 + eps*N(0,1)) and once per
+    element; returns max |x_final - x_final_unperturbed| / max|x_final| over
+    three seeds of each kind.  Values >> 1e-4 mean the reference does not reproduce its own
+    pixels to 1e-4 under legitimate rounding differences (e.g. 1 vs 8 MKL
+    threads), so tests scale the per-pixel tolerance by this number.
+    """
+    model = ocm.OracleModel(ocm.vgg_program(weights, cfg), style_layers, content_layers)
+    model.set_targets(style, content)
+
+    def run(seed, elementwise=False):
+        gen = torch.Generator().manual_seed(seed)
+
+        def lg(x):
+            s, c, t, g = ocm.loss_and_grad(model, x, style_w, content_w)
+            if seed and elementwise:
+                g = g * (1 + eps * torch.randn(g.shape, generator=gen))
+            elif seed:
+                g = g * (1 + eps * float(torch.randn((), generator=gen)))
+            return s, c, t, g
+        return optim_ref.run_loop(lg, x0, steps, optimizer=optimizer,
+                                  lr=adam_lr if optimizer == "adam" else None)["x"]
+    base = run(0)
+    scale = float(base.abs().max())
+    return max(float((run(s, ew) - base).abs().max()) / scale for s in (1, 2, 3) for ew in (False, True))
 
 
 def run_case(ref, name, *, cfg, cfg_name, wseed, hw_content, hw_style, style_layers,
@@ -114,7 +147,11 @@ def run_case(ref, name, *, cfg, cfg_name, wseed, hw_content, hw_style, style_lay
                 f = x.reshape(b * c, h * w)
                 hits.append(int((torch.mm(f, f.t()) > 5e5).sum()))
 
+    sens = trajectory_sensitivity(weights, cfg, content, style, x0, style_layers=style_layers,
+                                  content_layers=content_layers, style_w=style_w, content_w=content_w,
+                                  steps=steps, optimizer=optimizer, adam_lr=adam_lr)
     arrays = {
+        "x_final_sensitivity": np.asarray(sens, dtype=np.float64),
         "x0": x0.numpy(),
         "x_final": out_img.detach().numpy(),
         "grad_step1": grads["g1"].numpy(),
@@ -153,7 +190,7 @@ def run_case(ref, name, *, cfg, cfg_name, wseed, hw_content, hw_style, style_lay
     g1 = grads["g1"]
     print(f"{name}: total {history['total_loss'][0]:.6e} -> {history['total_loss'][-1]:.6e} "
           f"|g1|max {g1.abs().max():.3e} clamp_hits {hits} closures {runner._closure_calls} "
-          f"size {os.path.getsize(path) / 1024:.0f} KiB")
+          f"sens {sens:.1e} size {os.path.getsize(path) / 1024:.0f} KiB")
     assert g1.abs().max() > 1e-7, "degenerate fixture: L-BFGS would early-return"
 
 
@@ -208,6 +245,9 @@ def main():
     run_case(ref, "vgg19_white_lbfgs", cfg=synthetic.VGG19_CFG, cfg_name="vgg19", wseed=0,
              hw_content=(64, 64), hw_style=(64, 96), style_layers=S, content_layers=C,
              init_method="white", steps=3, optimizer="lbfgs", subsample_targets=True)
+    run_case(ref, "vgg19_content_lbfgs", cfg=synthetic.VGG19_CFG, cfg_name="vgg19", wseed=0,
+             hw_content=(64, 64), hw_style=(64, 96), style_layers=S, content_layers=C,
+             init_method="content", steps=4, optimizer="lbfgs", style_w=1e8, subsample_targets=True)
 
 
 if __name__ == "__main__":

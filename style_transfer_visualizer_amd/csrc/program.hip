@@ -85,7 +85,8 @@ extern "C" int stv_program_create(const stv_op_t* ops, int n_ops, stv_program** 
 extern "C" int stv_program_run(stv_program* prog, int use_graph, void* stream) {
   if (!prog) return STV_ERR_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (!use_graph) return run_all(prog, stream);
+  // The legacy default stream cannot be captured: run eagerly there.
+  if (!use_graph || st == nullptr) return run_all(prog, stream);
   if (prog->exec && prog->captured_on != st) {
     (void)hipGraphExecDestroy(prog->exec);
     (void)hipGraphDestroy(prog->graph);
@@ -96,16 +97,21 @@ extern "C" int stv_program_run(stv_program* prog, int use_graph, void* stream) {
     // Eager warm-up first: one-time hipFuncSetAttribute calls must not land inside a capture.
     int rc = run_all(prog, stream);
     if (rc != STV_OK) return rc;
-    if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) return STV_ERR_GRAPH;
+    if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+      (void)hipGetLastError();  // do not leave a sticky error behind for the caller's runtime
+      return STV_ERR_GRAPH;
+    }
     rc = run_all(prog, stream);
     hipGraph_t g = nullptr;
     if (hipStreamEndCapture(st, &g) != hipSuccess || rc != STV_OK) {
       if (g) (void)hipGraphDestroy(g);
+      (void)hipGetLastError();
       return rc != STV_OK ? rc : STV_ERR_GRAPH;
     }
     hipGraphExec_t e = nullptr;
     if (hipGraphInstantiate(&e, g, nullptr, nullptr, 0) != hipSuccess) {
       (void)hipGraphDestroy(g);
+      (void)hipGetLastError();
       return STV_ERR_GRAPH;
     }
     prog->graph = g;
@@ -116,6 +122,32 @@ extern "C" int stv_program_run(stv_program* prog, int use_graph, void* stream) {
   if (hipGraphLaunch(prog->exec, st) != hipSuccess) return STV_ERR_GRAPH;
   return STV_OK;
 }
+
+// Eager run with a HIP event pair around every op, recorded on the stream the
+// kernels are launched on; ms_out[i] = device time of op i.  Synchronises at
+// the end (measurement helper for bench.py, never used on the step path).
+extern "C" int stv_program_profile(stv_program* prog, void* stream, float* ms_out, int n_out) {
+  if (!prog || !ms_out || n_out < (int)prog->ops.size()) return STV_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const size_t n = prog->ops.size();
+  std::vector<hipEvent_t> ev(n + 1);
+  for (auto& e : ev)
+    if (hipEventCreate(&e) != hipSuccess) return STV_ERR_ALLOC;
+  int rc = STV_OK;
+  (void)hipEventRecord(ev[0], st);
+  for (size_t i = 0; i < n && rc == STV_OK; ++i) {
+    rc = run_op(prog->ops[i], stream);
+    (void)hipEventRecord(ev[i + 1], st);
+  }
+  if (hipStreamSynchronize(st) != hipSuccess) rc = STV_ERR_LAUNCH;
+  if (rc == STV_OK)
+    for (size_t i = 0; i < n; ++i)
+      if (hipEventElapsedTime(&ms_out[i], ev[i], ev[i + 1]) != hipSuccess) rc = STV_ERR_LAUNCH;
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  return rc;
+}
+
+extern "C" int stv_program_op_count(const stv_program* prog) { return prog ? (int)prog->ops.size() : 0; }
 
 extern "C" void stv_program_destroy(stv_program* prog) {
   if (!prog) return;

@@ -166,6 +166,7 @@ class OptimizationRunner:
             self._progress_bar = tqdm(total=self.total_steps, desc="Style Transfer")
             self._owns_progress_bar = True
         started = time.time()
+        side = self._enter_side_stream()
         try:
             while self._step_index < self.total_steps:
                 step_idx = self._step_index + 1
@@ -184,6 +185,7 @@ class OptimizationRunner:
                 self._finalize_step(recorded)
                 self._pending_step_tensors = None
         finally:
+            self._leave_side_stream(side)
             self._cleanup()
         elapsed = time.time() - started
         self._log_optimization_summary()
@@ -194,6 +196,24 @@ class OptimizationRunner:
         return self.input_img, history, elapsed
 
     # ------------------------------------------------------------------- set-up
+    def _enter_side_stream(self):
+        """GPU runs use a non-default HIP stream so the fused step can replay as a hipGraph
+        (the legacy default stream cannot be captured)."""
+        if not (self._fused and self.input_img.is_cuda):
+            return None
+        side = torch.cuda.Stream(device=self.input_img.device)
+        side.wait_stream(torch.cuda.current_stream(self.input_img.device))
+        ctx = torch.cuda.stream(side)
+        ctx.__enter__()
+        return side, ctx
+
+    def _leave_side_stream(self, entered) -> None:
+        if entered is None:
+            return
+        side, ctx = entered
+        ctx.__exit__(None, None, None)
+        torch.cuda.current_stream(self.input_img.device).wait_stream(side)
+
     def _build_optimizer(self, optimizer_factory: Callable[[torch.Tensor], Optimizer] | None) -> Optimizer:
         if optimizer_factory is not None:
             return optimizer_factory(self.input_img)

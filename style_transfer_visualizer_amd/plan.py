@@ -294,11 +294,21 @@ class Program:
         _lib.check(lib.stv_program_create(arr, len(op_list), ctypes.byref(handle)), "stv_program_create")
         self._handle = handle
         self.n_ops = len(op_list)
+        self.op_meta = [(int(o.op), int(o.H), int(o.W), int(o.cin), int(o.cout), int(o.taps), int(o.n))
+                        for o in op_list]
 
     def run(self, use_graph: bool = False) -> None:
         lib = _lib.load()
         _lib.check(lib.stv_program_run(self._handle, 1 if use_graph else 0,
                                        torch.cuda.current_stream().cuda_stream), "stv_program_run")
+
+    def profile(self) -> list[float]:
+        """Per-op device milliseconds (HIP events on the current stream); synchronises."""
+        lib = _lib.load()
+        out = (ctypes.c_float * self.n_ops)()
+        _lib.check(lib.stv_program_profile(self._handle, torch.cuda.current_stream().cuda_stream, out,
+                                           self.n_ops), "stv_program_profile")
+        return list(out)
 
     def __del__(self) -> None:
         try:

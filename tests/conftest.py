@@ -59,13 +59,22 @@ class GoldenCase:
         style = synthetic.synthetic_image(1, *m["hw_style"], normalize=m["normalize"])
         return content, style
 
+    def pixel_tolerance(self) -> float:
+        """Per-pixel tolerance for x_final, relative to max|x_final|.
+
+        north_star asks for 1e-4; a fixture whose trajectory amplifies 2-ulp gradient
+        differences beyond that (``x_final_sensitivity``, see oracle/make_golden.py)
+        gets 4x its measured sensitivity instead.
+        """
+        return max(1e-4, 4.0 * float(self.arrays["x_final_sensitivity"]))
+
     def tensor(self, key: str) -> torch.Tensor:
         return torch.from_numpy(np.asarray(self.arrays[key]))
 
 
 GOLDEN_CASES = [
     "mini_white_lbfgs", "mini_content_lbfgs", "mini_random_lbfgs_nonorm",
-    "mini_white_adam", "mini_clamp_lbfgs", "tiny_taps_lbfgs", "vgg19_white_lbfgs",
+    "mini_white_adam", "mini_clamp_lbfgs", "tiny_taps_lbfgs", "vgg19_white_lbfgs", "vgg19_content_lbfgs",
 ]
 
 

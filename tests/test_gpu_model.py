@@ -108,12 +108,46 @@ def test_trajectory_matches_reference(golden_case: GoldenCase, monkeypatch):
     assert [s for s, has in seen if has] == case.arrays["logged_steps"].tolist()
     assert runner._closure_calls == int(case.arrays["closure_calls"])
     assert len(history["total_loss"]) == steps
-    # losses per step and final image
-    np.testing.assert_allclose(history["total_loss"], case.arrays["total_loss"], rtol=1e-3)
-    np.testing.assert_allclose(history["style_loss"], case.arrays["style_loss"], rtol=1e-3)
-    np.testing.assert_allclose(history["content_loss"], case.arrays["content_loss"], rtol=1e-3)
+    # losses per step and final image.  Tolerance: north_star's 1e-4 per pixel, widened only for
+    # fixtures whose reference trajectory itself amplifies 2-ulp gradient noise beyond that
+    # (GoldenCase.pixel_tolerance / oracle.make_golden.trajectory_sensitivity).
+    ptol = case.pixel_tolerance()
+    ltol = max(1e-3, ptol)
+    np.testing.assert_allclose(history["total_loss"], case.arrays["total_loss"], rtol=ltol)
+    np.testing.assert_allclose(history["style_loss"], case.arrays["style_loss"], rtol=ltol)
+    np.testing.assert_allclose(history["content_loss"], case.arrays["content_loss"], rtol=ltol)
     xf = case.arrays["x_final"]
-    np.testing.assert_allclose(out.detach().cpu().numpy(), xf, rtol=0, atol=1e-4 * np.abs(xf).max())
+    np.testing.assert_allclose(out.detach().cpu().numpy(), xf, rtol=0, atol=ptol * np.abs(xf).max())
+
+
+@pytest.mark.parametrize("name", ["mini_content_lbfgs", "mini_random_lbfgs_nonorm", "vgg19_content_lbfgs"])
+def test_every_step_matches_oracle_at_same_image(name, monkeypatch):
+    """Chaos-free parity: at every step of a HIP-driven run, evaluate the CPU oracle at the SAME
+    image and compare losses and gradient (fp32 rounding level), and compare the device L-BFGS
+    update with the oracle optimizer fed the same gradients."""
+    from oracle import optim_ref
+    from style_transfer_visualizer_amd import ops
+    case = GoldenCase(name)
+    m = case.meta
+    cfg, model, x, _ = _build(case, monkeypatch)
+    oracle = ocm.OracleModel(ocm.vgg_program(case.weights(), case.cfg), m["style_layers"], m["content_layers"])
+    content, style = case.images()
+    oracle.set_targets(style, content)
+    x_twin = x.detach().cpu().clone()                      # oracle optimizer fed HIP gradients
+    twin = optim_ref.LbfgsRef(x_twin.view(-1), lr=1.0)
+    state, work = ops.lbfgs_alloc(x.numel(), 100, DEV)
+    for step in range(m["steps"]):
+        s, c, t = model.loss_and_grad(x, m["style_w"], m["content_w"])
+        so, co, to, go = ocm.loss_and_grad(oracle, x.detach().cpu(), m["style_w"], m["content_w"])
+        assert float(t) == pytest.approx(float(to), rel=1e-5)
+        assert float(s) == pytest.approx(float(so), rel=1e-5)
+        assert float(c) == pytest.approx(float(co), rel=1e-5)
+        g = x.grad.detach().cpu()
+        assert float((g - go).abs().max() / go.abs().max()) < 3e-5, f"step {step + 1}"
+        twin.step(lambda: (t.cpu(), g))
+        ops.lbfgs_step(x.detach(), x.grad, state, work, 100, min(step, 100), 1.0)
+        drift = float((x.detach().cpu() - x_twin).abs().max() / x_twin.abs().max())
+        assert drift < 2e-6, f"device L-BFGS left the oracle optimizer at step {step + 1}: {drift:.2e}"
 
 
 def test_bf16_storage_tracks_fp32(monkeypatch):
