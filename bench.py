@@ -157,6 +157,14 @@ def run_gpu(args, rank: int, world: int, device: torch.device, size: int, steps:
             e["launches"] += 1
             if meta[0] == OP["CONV"]:
                 e["flops"] += conv_flops(meta)
+        if args.per_op:
+            names = {v: k for k, v in OP.items()}
+            with open(args.per_op, "a") as f:
+                f.write(f"# size {size} precision {args.precision}\n")
+                for meta, t in zip(prog.op_meta, ms, strict=True):
+                    fl = conv_flops(meta) if meta[0] == OP["CONV"] else 0.0
+                    f.write(f"{names.get(meta[0], meta[0]):18s} H{meta[1]:5d} W{meta[2]:5d} cin{meta[3]:4d} cout{meta[4]:4d} "
+                            f"taps{meta[5]} n{meta[6]:9d}  {t * 1e3:9.1f} us  {fl / (t * 1e-3) / 1e12 if t > 0 else 0:8.1f} TF/s\n")
         dom_name, dom = max(groups.items(), key=lambda kv: kv[1]["ms"])
         peak = BF16_PEAK_TFLOPS if args.precision == "bf16" else FP32_PEAK_TFLOPS
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
@@ -220,6 +228,7 @@ def main() -> None:
     ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the additional 1024x1024 measurement")
+    ap.add_argument("--per-op", default=None, help="append a per-op device-time table to this file")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

@@ -8,8 +8,11 @@
 // input and the [taps][BN] weight rows for that channel slice in LDS, then
 // every wave walks the 9 taps as shifted windows of the same LDS tile, so the
 // input is fetched ~1.3x (halo) instead of 9x.  Global loads for stage s+1 are
-// issued before the MFMAs of stage s and written to the other LDS buffer after
-// them (issue-early / write-late), one barrier per stage.
+// issued (raw buffer loads: the hardware range check zero-fills halo / channel
+// padding, so there is no branch or select in front of the data) before the
+// MFMAs of stage s; their ds_writes into the other LDS buffer are spread over
+// the later taps' MFMA groups, so neither the HBM/L2 latency nor the LDS write
+// sits on the critical path.  One barrier per stage.
 //
 // MFMA shapes: bf16 -> v_mfma_f32_32x32x16_bf16 (lane (r,h) holds k = 8h..8h+7),
 //              fp32 -> v_mfma_f32_32x32x2_f32 x4 with lane (r,h) holding
@@ -19,6 +22,10 @@
 //
 // The same kernel computes the input gradient (dgrad) when handed the flipped,
 // transposed weights, and the Gram backward product dF = F * S as a 1x1 conv.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "stv_common.h"
 
 namespace {
@@ -38,6 +45,8 @@ struct Cfg {
   static constexpr int W_ROWS = TAPS * BN;
   static constexpr int W_BYTES = W_ROWS * ROWB;
   static constexpr int STAGE_BYTES = IN_BYTES + W_BYTES;
+  static constexpr int PARK_ROWS = (IN_PIX + W_ROWS < 256) ? IN_PIX + W_ROWS : 256;  // idle staging lanes
+                                                                                       // write into row padding
   static constexpr int MT = TH / WM;
   static constexpr int NT = BN / WN / 32;
   static constexpr int THREADS = 256;
@@ -104,8 +113,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   const T* __restrict__ wgt = static_cast<const T*>(a.w);
   const bool relu_in = (a.flags & STV_RELU_IN) != 0;
 
-  // ---- per-thread staging descriptors (element offsets, -1 = zero fill) ----
-  int in_off[C::IN_ITERS];
+  // ---- per-thread staging descriptors: byte offsets, OOB -> zero fill by the buffer range check ----
+  constexpr uint32_t kOob = 0x80000000u;   // >= num_records for every tensor this kernel accepts
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T*>(xin), 0, a.H * a.W * a.cin * (int)sizeof(T), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T*>(wgt), 0, C::TAPS * a.cout * a.cin * (int)sizeof(T), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_null = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(xin), 0, 0, 0x00020000);
+  const uint32_t relu_enable = relu_in ? 0xFFFFFFFFu : 0u;
+  uint32_t in_off[C::IN_ITERS];
   int in_lds[C::IN_ITERS];
 #pragma unroll
   for (int it = 0; it < C::IN_ITERS; ++it) {
@@ -114,10 +130,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const int py = pix / C::IN_W, px = pix - py * C::IN_W;
     const int gy = y0 + py - C::HALO, gx = x0 + px - C::HALO;
     const bool ok = (v < C::IN_VECS) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-    in_off[it] = ok ? ((gy * a.W + gx) * a.cin + half * kVec) : -1;
-    in_lds[it] = (v < C::IN_VECS) ? (pix * C::ROWB + half * 16) : -1;
+    in_off[it] = ok ? (uint32_t)(((gy * a.W + gx) * a.cin + half * kVec) * (int)sizeof(T)) : kOob;
+    in_lds[it] = (v < C::IN_VECS) ? pix * C::ROWB + half * 16 : (tid % C::PARK_ROWS) * C::ROWB + C::KB;
   }
-  int w_off[C::W_ITERS];
+  uint32_t w_off[C::W_ITERS];
   int w_lds[C::W_ITERS];
 #pragma unroll
   for (int it = 0; it < C::W_ITERS; ++it) {
@@ -125,34 +141,38 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const int row = v >> 1, half = v & 1;
     const int tap = row / C::BN, n = row - tap * C::BN;
     const bool ok = (v < C::W_VECS) && (n0 + n) < a.cout;
-    w_off[it] = ok ? ((tap * a.cout + n0 + n) * a.cin + half * kVec) : -1;
-    w_lds[it] = (v < C::W_VECS) ? (C::IN_BYTES + row * C::ROWB + half * 16) : -1;
+    w_off[it] = ok ? (uint32_t)(((tap * a.cout + n0 + n) * a.cin + half * kVec) * (int)sizeof(T)) : kOob;
+    w_lds[it] = (v < C::W_VECS) ? C::IN_BYTES + row * C::ROWB + half * 16 : (tid % C::PARK_ROWS) * C::ROWB + C::KB;
   }
 
-  u32x4 in_reg[C::IN_ITERS];
-  u32x4 w_reg[C::W_ITERS];
-  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  // Two register sets: data of K-stage k lives in set (k & 1).  Stage c issues the loads of
+  // stage c+2 and writes the set loaded one stage earlier (stage c+1) into the other LDS
+  // buffer, so every global load has more than a full stage of MFMA work to land.
+  u32x4 in_reg[2][C::IN_ITERS];
+  u32x4 w_reg[2][C::W_ITERS];
 
-  auto stage_load = [&](int c0) {
+  // `live` = false turns every load into an out-of-range one (zero records): no traffic, no branch
+  auto stage_load = [&](auto par, int c0, bool live) {
+    constexpr int P = decltype(par)::value;
+    const uint32_t cb = (uint32_t)(c0 * (int)sizeof(T));
+    const __amdgpu_buffer_rsrc_t rx = live ? rs_x : rs_null;
+    const __amdgpu_buffer_rsrc_t rw = live ? rs_w : rs_null;
 #pragma unroll
     for (int it = 0; it < C::IN_ITERS; ++it)
-      in_reg[it] = (in_off[it] >= 0)
-                       ? *reinterpret_cast<const u32x4*>(xin + in_off[it] + c0)
-                       : zero4;
+      in_reg[P][it] = __builtin_amdgcn_raw_buffer_load_b128(rx, in_off[it] + cb, 0, 0);
 #pragma unroll
     for (int it = 0; it < C::W_ITERS; ++it)
-      w_reg[it] = (w_off[it] >= 0)
-                      ? *reinterpret_cast<const u32x4*>(wgt + w_off[it] + c0)
-                      : zero4;
+      w_reg[P][it] = __builtin_amdgcn_raw_buffer_load_b128(rw, w_off[it] + cb, 0, 0);
   };
-  auto stage_write = [&](char* buf) {
-#pragma unroll
-    for (int it = 0; it < C::IN_ITERS; ++it)
-      if (in_lds[it] >= 0)
-        *reinterpret_cast<u32x4*>(buf + in_lds[it]) = relu_in ? relu16<T>(in_reg[it]) : in_reg[it];
-#pragma unroll
-    for (int it = 0; it < C::W_ITERS; ++it)
-      if (w_lds[it] >= 0) *reinterpret_cast<u32x4*>(buf + w_lds[it]) = w_reg[it];
+  // write staged vector number `k` (inputs first, then weights); branch-free: ReLU-on-load
+  // clears elements whose sign bit is set under a wave-uniform enable mask
+  auto stage_write_one = [&](auto par, char* buf, int k) {
+    constexpr int P = decltype(par)::value;
+    if (k < C::IN_ITERS) {
+      *reinterpret_cast<u32x4*>(buf + in_lds[k]) = relu16_masked<T>(in_reg[P][k], relu_enable);
+    } else {
+      *reinterpret_cast<u32x4*>(buf + w_lds[k - C::IN_ITERS]) = w_reg[P][k - C::IN_ITERS];
+    }
   };
 
   f32x16 acc[C::MT][C::NT];
@@ -168,37 +188,73 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   const int b_lane = C::IN_BYTES + (wn * (C::NT * 32) + r) * C::ROWB + h * 16;
 
   const int nchunks = a.cin / C::CK;
-  stage_load(0);
-  stage_write(smem);
-  __syncthreads();
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  constexpr int NW = C::IN_ITERS + C::W_ITERS;
 
-  for (int c = 0; c < nchunks; ++c) {
-    char* cur = smem + (c & 1) * C::STAGE_BYTES;
-    char* nxt = smem + ((c + 1) & 1) * C::STAGE_BYTES;
-    const bool more = (c + 1) < nchunks;
-    if (more) stage_load((c + 1) * C::CK);
+  // one K-stage with compile-time parity P = c & 1
+  auto run_stage = [&](auto par, int c) {
+    constexpr int P = decltype(par)::value;
+    using Other = std::integral_constant<int, P ^ 1>;
+    char* cur = smem + P * C::STAGE_BYTES;
+    char* nxt = smem + (P ^ 1) * C::STAGE_BYTES;
+    stage_load(par, (c + 2) * C::CK, (c + 2) < nchunks);   // set P is free: its data is in `cur`
+    __builtin_amdgcn_sched_barrier(0);                     // keep the prefetch above the MFMA stream
 
-#pragma unroll
-    for (int tap = 0; tap < C::TAPS; ++tap) {
+    // fragments are software-pipelined one tap ahead (two register sets, static indices)
+    FragT bf[2][C::NT];
+    FragT af[2][C::MT];
+    auto load_frags = [&](int tap, int set) {
       const int dy = (C::TAPS == 9) ? tap / 3 : 0;
       const int dx = (C::TAPS == 9) ? tap % 3 : 0;
-      FragT bf[C::NT];
-      FragT af[C::MT];
 #pragma unroll
       for (int nt = 0; nt < C::NT; ++nt)
-        bf[nt] = *reinterpret_cast<const FragT*>(cur + b_lane + (tap * C::BN + nt * 32) * C::ROWB);
+        bf[set][nt] = *reinterpret_cast<const FragT*>(cur + b_lane + (tap * C::BN + nt * 32) * C::ROWB);
 #pragma unroll
       for (int mt = 0; mt < C::MT; ++mt)
-        af[mt] = *reinterpret_cast<const FragT*>(cur + a_lane + ((mt + dy) * C::IN_W + dx) * C::ROWB);
+        af[set][mt] = *reinterpret_cast<const FragT*>(cur + a_lane + ((mt + dy) * C::IN_W + dx) * C::ROWB);
+    };
+    load_frags(0, 0);
+#pragma unroll
+    for (int tap = 0; tap < C::TAPS; ++tap) {
+      const int set = tap & 1;
+      if (tap + 1 < C::TAPS) load_frags(tap + 1, set ^ 1);
+      // issue the next tap's LDS reads first, then this tap's MFMAs back to back: the reads
+      // (counted lgkmcnt) complete under the matrix work of a wave that has no SIMD partner
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < C::NT; ++nt) mma<T>(af[mt], bf[nt], acc[mt][nt]);
+        for (int nt = 0; nt < C::NT; ++nt) mma<T>(af[set][mt], bf[set][nt], acc[mt][nt]);
+      // spread stage c+1's LDS writes (set P^1, loaded during stage c-1) over the MFMA groups
+      if (C::TAPS == 9) {
+        constexpr int PER = (NW + 8) / 9;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = tap * PER; k < (tap + 1) * PER; ++k)
+          if (k < NW) stage_write_one(Other{}, nxt, k);
+      }
     }
-
-    if (more) stage_write(nxt);
+    if (C::TAPS != 9) {
+#pragma unroll
+      for (int k = 0; k < NW; ++k) stage_write_one(Other{}, nxt, k);
+    }
     __syncthreads();
+  };
+
+  // prologue: stage 0 -> LDS buffer 0, stage 1 in flight in set 1
+  stage_load(P0{}, 0, true);
+  stage_load(P1{}, C::CK, 1 < nchunks);
+#pragma unroll
+  for (int k = 0; k < NW; ++k) stage_write_one(P0{}, smem, k);
+  __syncthreads();
+
+  int c = 0;
+  for (; c + 1 < nchunks; c += 2) {
+    run_stage(P0{}, c);
+    run_stage(P1{}, c + 1);
   }
+  if (c < nchunks) run_stage(P0{}, c);
 
   // ---- epilogue: accumulators -> LDS C tile (fp32) -> 16-byte vector stores ----
   float* cs = reinterpret_cast<float*>(smem);
@@ -323,12 +379,29 @@ int launch_typed(const ConvArgs& a, hipStream_t st) {
     STV_CHECK_LAUNCH();
     return STV_OK;
   }
-  if (a.cout <= 64) {
-    if (a.H <= 4) return launch_cfg<Cfg<T, 4, 64, 4, 1, TAPS>>(a, st);
-    return launch_cfg<Cfg<T, 8, 64, 4, 1, TAPS>>(a, st);
+  // Pick the tile that finishes first: waves of workgroups over 256 CUs x work per workgroup
+  // / relative efficiency of the tile (bigger tiles re-read fewer weights per FLOP).
+  struct Cand { int th, bn; float eff; };
+  const Cand cands[4] = {{8, 128, 1.0f}, {8, 64, 0.92f}, {4, 128, 0.76f}, {4, 64, 0.64f}};
+  int best = 0;
+  float best_cost = 3.4e38f;
+  for (int i = 0; i < 4; ++i) {
+    if (a.cout <= 64 && cands[i].bn == 128) continue;
+    const long blocks = (long)ceil_div(a.W, 32) * ceil_div(a.H, cands[i].th) * ceil_div(a.cout, cands[i].bn);
+    const float waves = (float)((blocks + 255) / 256);   // eff is per CU, whatever the residency
+    const float cost = waves * (float)(cands[i].th * cands[i].bn) / cands[i].eff;
+    if (cost < best_cost) { best_cost = cost; best = i; }
   }
-  if (a.H <= 4) return launch_cfg<Cfg<T, 4, 128, 1, 4, TAPS>>(a, st);
-  return launch_cfg<Cfg<T, 8, 128, 2, 2, TAPS>>(a, st);
+  if (const char* force = getenv("STV_CONV_CFG")) {   // tuning aid (tools/conv_sweep.py)
+    const int f = atoi(force);
+    if (f >= 0 && f < 4 && !(a.cout <= 64 && cands[f].bn == 128)) best = f;
+  }
+  switch (best) {
+    case 0: return launch_cfg<Cfg<T, 8, 128, 2, 2, TAPS>>(a, st);
+    case 1: return launch_cfg<Cfg<T, 8, 64, 4, 1, TAPS>>(a, st);
+    case 2: return launch_cfg<Cfg<T, 4, 128, 1, 4, TAPS>>(a, st);
+    default: return launch_cfg<Cfg<T, 4, 64, 2, 2, TAPS>>(a, st);
+  }
 }
 
 }  // namespace

@@ -95,6 +95,22 @@ template <> __device__ __forceinline__ u32x4 relu16<bf16_t>(u32x4 v) {
   return v;
 }
 
+// Branch-free ReLU: clear every element whose sign bit is set where `enable` is all-ones.
+template <typename T> __device__ __forceinline__ u32x4 relu16_masked(u32x4 v, uint32_t enable);
+template <> __device__ __forceinline__ u32x4 relu16_masked<float>(u32x4 v, uint32_t enable) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] &= ~((uint32_t)((int32_t)v[i] >> 31) & enable);
+  return v;
+}
+template <> __device__ __forceinline__ u32x4 relu16_masked<bf16_t>(u32x4 v, uint32_t enable) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t s = (v[i] >> 15) & 0x00010001u;
+    v[i] &= ~((s * 0xFFFFu) & enable);
+  }
+  return v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

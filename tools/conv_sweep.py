@@ -1,0 +1,35 @@
+"""Time stv_conv_igemm per tile config (STV_CONV_CFG) on VGG layer shapes (tuning aid)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from style_transfer_visualizer_amd import ops
+
+dev = torch.device("cuda")
+shapes = [(1024, 1024, 64, 64), (512, 512, 64, 128), (512, 512, 128, 128), (256, 256, 128, 256), (256, 256, 256, 256),
+          (128, 128, 256, 512), (128, 128, 512, 512), (64, 64, 512, 512), (32, 32, 512, 512)]
+dtype = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] == "bf16") else torch.float32
+names = ["8x128", "8x64", "4x128", "4x64"]
+for (H, W, cin, cout) in shapes:
+    x = torch.randn(H, W, cin, device=dev).to(dtype)
+    w = (torch.randn(9, cout, cin, device=dev) * 0.02).to(dtype)
+    b = torch.zeros(cout, device=dev)
+    y = torch.empty(H, W, cout, device=dev, dtype=dtype)
+    row = []
+    for cfg in range(4):
+        os.environ["STV_CONV_CFG"] = str(cfg)
+        if cout <= 64 and cfg in (0, 2):
+            row.append("   -  ")
+            continue
+        for _ in range(3):
+            ops.conv_igemm(x, w, b, out=y, flags=ops.RELU_OUT)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 20
+        e0.record()
+        for _ in range(n):
+            ops.conv_igemm(x, w, b, out=y, flags=ops.RELU_OUT)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / n
+        row.append(f"{2*9*cin*cout*H*W/ms/1e9:6.0f}")
+    print(f"{H:5d}x{W:<5d} {cin:4d}->{cout:<4d} TF/s by cfg " + "  ".join(f"{n}:{v}" for n, v in zip(names, row)), flush=True)
