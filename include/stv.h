@@ -133,6 +133,14 @@ size_t stv_lbfgs_workspace_bytes(size_t n, int history);
 int stv_lbfgs_step(float* x, const float* grad, void* state, void* workspace, size_t n,
                    int history, int m_max, float lr, float tol_grad, float tol_change,
                    void* stream);
+/* Same update with the history read twice per step instead of through 2m dependent
+ * passes (inner products of {s_i},{y_i},g kept in S x S tables; see lbfgs_compact.hip).
+ * Own state/workspace layout; both zero-initialised by the caller. */
+size_t stv_lbfgsc_state_bytes(int history);
+size_t stv_lbfgsc_workspace_bytes(size_t n, int history);
+int stv_lbfgsc_step(float* x, const float* grad, void* state, void* workspace, size_t n,
+                    int history, int m_max, float lr, float tol_grad, float tol_change,
+                    void* stream);
 /* scalars are computed in double on the host exactly as torch does
  * (1-beta1, 1-beta2, 1-beta1**t, sqrt(1-beta2**t)) and passed rounded to fp32 */
 int stv_adam_step(float* x, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,

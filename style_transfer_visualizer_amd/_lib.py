@@ -59,6 +59,9 @@ SIGNATURES = {
     "stv_lbfgs_state_bytes": (c_size_t, [c_int]),
     "stv_lbfgs_workspace_bytes": (c_size_t, [c_size_t, c_int]),
     "stv_lbfgs_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_float, c_float, c_float, c_void_p]),
+    "stv_lbfgsc_state_bytes": (c_size_t, [c_int]),
+    "stv_lbfgsc_workspace_bytes": (c_size_t, [c_size_t, c_int]),
+    "stv_lbfgsc_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_float, c_float, c_float, c_void_p]),
     "stv_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float, c_float, c_float, c_float, c_float, c_void_p]),
     "stv_program_create": (c_int, [ctypes.POINTER(StvOp), c_int, ctypes.POINTER(c_void_p)]),
     "stv_program_run": (c_int, [c_void_p, c_int, c_void_p]),

@@ -15,6 +15,8 @@
 //                    partial sums, and the backward seed
 //                    S = k * [R <= clamp] * (G - T)  (symmetric), so that
 //                    dF^T = F^T * S is a plain 1x1 conv (stv_conv_igemm taps=1).
+#include <type_traits>
+
 #include "stv_common.h"
 
 namespace {
@@ -141,34 +143,194 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(const T* __restrict__
       }
 }
 
-// 64 consecutive Gram elements per block; 4 ks-slices reduced through LDS in a
-// fixed order.  loss_part gets one partial per block.
+// ---- bf16 features: v_mfma_f32_32x32x16_bf16 fed by transposing LDS reads -------------------------
+// The contraction runs over pixels while memory is pixel-major, so each MFMA operand needs, per
+// lane, 8 consecutive PIXELS of one channel.  ds_read_b64_tr_b16 delivers exactly that: a 16-lane
+// group reads a 4-pixel x 16-channel block (lane 4q+p supplies the address of row q, channels
+// 4p..4p+3) and lane i receives channel i of the 4 rows.  bf16 x bf16 products are exact in fp32
+// and the MFMA accumulates in fp32, so this is still an fp32-accumulated Gram of the stored
+// features; it turns the kernel from fp32-MFMA-bound into an HBM stream.
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+constexpr int PKB = 64;   // pixels per LDS stage (bf16 path)
+
+template <int TS>
+struct GramBCfg {
+  static constexpr int AT = TS / 64;
+  static constexpr int PITCH = TS * 2 + 64;            // bytes; = 64 (mod 256): tr reads conflict-free
+  static constexpr int TILE_BYTES = PKB * PITCH;
+  static constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+  static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+};
+
+template <int TS>
+__global__ __launch_bounds__(256) void gram_partial_bf16_kernel(const bf16_t* __restrict__ F,
+                                                                float* __restrict__ partials, int N, int C,
+                                                                int ksplit, int chunk) {
+  using G = GramBCfg<TS>;
+  constexpr int VPR = TS / 8;                 // 16-byte vectors per tile row
+  constexpr int VECS = PKB * VPR;
+  constexpr int ITERS = VECS / 256;
+  static_assert(VECS % 256 == 0, "whole iterations");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int nt = (C + TS - 1) / TS;
+  int ti = 0, rem = blockIdx.x;
+  while (rem >= nt - ti) { rem -= nt - ti; ++ti; }
+  const int tj = ti + rem;
+  const bool same = ti == tj;
+  const int i0 = ti * TS, j0 = tj * TS;
+  const int ks = blockIdx.y;
+  const int p_begin = ks * chunk;
+  const int p_end = min(N, p_begin + chunk);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wi = wave >> 1, wj = wave & 1;
+  const int grp = lane >> 4, lam = lane & 15;
+  // byte offset of this lane's tr-read address inside a tile, for k-step 0 / first half
+  const int tr_lane = ((grp >> 1) * 8 + (lam >> 2)) * G::PITCH + ((grp & 1) * 16 + (lam & 3) * 4) * 2;
+
+  f32x16 acc[G::AT][G::AT];
+#pragma unroll
+  for (int a = 0; a < G::AT; ++a)
+#pragma unroll
+    for (int b = 0; b < G::AT; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(F), 0, N * C * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_null = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(F), 0, 0, 0x00020000);
+  constexpr uint32_t kOob = 0x80000000u;
+  uint32_t off_i[ITERS], off_j[ITERS];
+  int lds_off[ITERS];
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int v = it * 256 + tid;
+    const int pr = v / VPR, cv = (v % VPR) * 8;
+    lds_off[it] = pr * G::PITCH + cv * 2;
+    off_i[it] = (i0 + cv < C) ? (uint32_t)((pr * C + i0 + cv) * 2) : kOob;
+    off_j[it] = (j0 + cv < C) ? (uint32_t)((pr * C + j0 + cv) * 2) : kOob;
+  }
+  u32x4 reg_i[ITERS], reg_j[ITERS];
+  auto stage_load = [&](int p0, bool live) {
+    // rows past p_end must read as zero: clamp through the record count of a per-stage descriptor
+    const int rows = min(PKB, p_end - p0);
+    const __amdgpu_buffer_rsrc_t r =
+        (live && rows > 0) ? __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(F) + (size_t)p0 * C, 0,
+                                                               rows * C * 2, 0x00020000)
+                           : rs_null;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      reg_i[it] = __builtin_amdgcn_raw_buffer_load_b128(r, off_i[it], 0, 0);
+      if (!same) reg_j[it] = __builtin_amdgcn_raw_buffer_load_b128(r, off_j[it], 0, 0);
+    }
+  };
+  auto stage_write = [&](char* buf) {
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      *reinterpret_cast<u32x4*>(buf + lds_off[it]) = reg_i[it];
+      if (!same) *reinterpret_cast<u32x4*>(buf + G::TILE_BYTES + lds_off[it]) = reg_j[it];
+    }
+  };
+  (void)rs;
+
+  const int nstages = (p_end > p_begin) ? (p_end - p_begin + PKB - 1) / PKB : 0;
+  stage_load(p_begin, nstages > 0);
+  stage_write(smem);
+  __syncthreads();
+  for (int s = 0; s < nstages; ++s) {
+    char* cur = smem + (s & 1) * G::STAGE_BYTES;
+    char* nxt = smem + ((s + 1) & 1) * G::STAGE_BYTES;
+    stage_load(p_begin + (s + 1) * PKB, (s + 1) < nstages);
+    __builtin_amdgcn_sched_barrier(0);
+    const char* ta = cur + tr_lane + (wi * (G::AT * 32)) * 2;
+    const char* tb = cur + (same ? 0 : G::TILE_BYTES) + tr_lane + (wj * (G::AT * 32)) * 2;
+#pragma unroll
+    for (int kk = 0; kk < PKB / 16; ++kk) {
+      bf16x8v af[G::AT], bfr[G::AT];
+#pragma unroll
+      for (int a = 0; a < G::AT; ++a) {
+        const char* pa = ta + kk * 16 * G::PITCH + a * 64;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pa));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pa + 4 * G::PITCH));
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        af[a] = __builtin_bit_cast(bf16x8v, v);
+      }
+#pragma unroll
+      for (int b = 0; b < G::AT; ++b) {
+        const char* pb = tb + kk * 16 * G::PITCH + b * 64;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pb));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pb + 4 * G::PITCH));
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        bfr[b] = __builtin_bit_cast(bf16x8v, v);
+      }
+#pragma unroll
+      for (int a = 0; a < G::AT; ++a)
+#pragma unroll
+        for (int b = 0; b < G::AT; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    stage_write(nxt);
+    __syncthreads();
+  }
+
+  const int r = lane & 31, h = lane >> 5;
+  float* out = partials + (size_t)ks * C * C;
+#pragma unroll
+  for (int a = 0; a < G::AT; ++a)
+#pragma unroll
+    for (int b = 0; b < G::AT; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = i0 + wi * (G::AT * 32) + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        const int col = j0 + wj * (G::AT * 32) + b * 32 + r;
+        if (row < C && col < C) out[(size_t)row * C + col] = acc[a][b][i];
+      }
+}
+
+// FIN_E consecutive Gram elements per block, FIN_S ks-slices each, reduced through LDS in a
+// fixed order (deterministic).  loss_part gets one partial per block.
+constexpr int FIN_E = 32, FIN_S = 8;
 template <typename T>
 __global__ __launch_bounds__(256) void gram_finish_kernel(
     const float* __restrict__ partials, const float* __restrict__ target, float* __restrict__ gram_out,
     float* __restrict__ loss_part, T* __restrict__ sgrad, int C, int TS, int ksplit, float clamp_max,
     float norm, float k_grad, const float* __restrict__ coef_dev) {
-  __shared__ float red[4][64];
-  const int e = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int slice = threadIdx.x >> 6;
+  __shared__ float red[FIN_S][FIN_E];
+  const int le = threadIdx.x % FIN_E;
+  const int slice = threadIdx.x / FIN_E;
+  const int e = blockIdx.x * FIN_E + le;
   const int CC = C * C;
   float s = 0.0f;
-  int i = 0, j = 0;
   if (e < CC) {
-    i = e / C;
-    j = e - i * C;
+    const int i = e / C, j = e - i * C;
     // only tiles with tile(row) <= tile(col) were produced; mirror the rest
     const bool upper = (i / TS) <= (j / TS);
     const size_t src = upper ? ((size_t)i * C + j) : ((size_t)j * C + i);
-    for (int ks = slice; ks < ksplit; ks += 4) s += partials[(size_t)ks * CC + src];
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int ks = slice;
+    for (; ks + 3 * FIN_S < ksplit; ks += 4 * FIN_S) {
+      s0 += partials[(size_t)ks * CC + src];
+      s1 += partials[(size_t)(ks + FIN_S) * CC + src];
+      s2 += partials[(size_t)(ks + 2 * FIN_S) * CC + src];
+      s3 += partials[(size_t)(ks + 3 * FIN_S) * CC + src];
+    }
+    for (; ks < ksplit; ks += FIN_S) s0 += partials[(size_t)ks * CC + src];
+    s = (s0 + s1) + (s2 + s3);
   }
-  red[slice][threadIdx.x & 63] = s;
+  red[slice][le] = s;
   __syncthreads();
   if (slice == 0) {
-    const int t = threadIdx.x;
     float d2 = 0.0f;
     if (e < CC) {
-      const float R = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+      float R = 0.0f;
+#pragma unroll
+      for (int q = 0; q < FIN_S; ++q) R += red[q][le];
       const float Gv = fminf(R, clamp_max) / norm;
       if (gram_out) gram_out[e] = Gv;
       if (target) {
@@ -180,9 +342,28 @@ __global__ __launch_bounds__(256) void gram_finish_kernel(
         }
       }
     }
-    d2 = wave_sum(d2);
-    if (t == 0 && loss_part) loss_part[blockIdx.x] = d2;
+    // FIN_E = 32 active lanes of wave 0 (lanes 32..63 belong to slice 1 and stay out)
+#pragma unroll
+    for (int o = FIN_E / 2; o > 0; o >>= 1) d2 += __shfl_xor(d2, o, FIN_E);
+    if (le == 0 && loss_part) loss_part[blockIdx.x] = d2;
   }
+}
+
+template <int TS>
+int launch_bf16(const bf16_t* F, float* partials, int N, int C, int pairs, int ksplit, hipStream_t st) {
+  int chunk = ceil_div(N, ksplit);
+  chunk = ceil_div(chunk, PKB) * PKB;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_partial_bf16_kernel<TS>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, GramBCfg<TS>::LDS_BYTES) != hipSuccess)
+      return STV_ERR_LAUNCH;
+    attr = true;
+  }
+  hipLaunchKernelGGL((gram_partial_bf16_kernel<TS>), dim3(pairs, ksplit), dim3(256), GramBCfg<TS>::LDS_BYTES, st,
+                     F, partials, N, C, ksplit, chunk);
+  STV_CHECK_LAUNCH();
+  return STV_OK;
 }
 
 template <typename T>
@@ -191,6 +372,11 @@ int partial_typed(const void* F, float* partials, int N, int C, hipStream_t st) 
   const int nt = ceil_div(C, TS);
   const int pairs = nt * (nt + 1) / 2;
   const int ksplit = stv_gram_ksplit(N, C);
+  if (std::is_same<T, bf16_t>::value && (size_t)N * C * 2 < ((size_t)1 << 31)) {
+    const bf16_t* Fb = static_cast<const bf16_t*>(F);
+    return TS == 64 ? launch_bf16<64>(Fb, partials, N, C, pairs, ksplit, st)
+                    : launch_bf16<128>(Fb, partials, N, C, pairs, ksplit, st);
+  }
   int chunk = ceil_div(N, ksplit);
   chunk = ceil_div(chunk, PK) * PK;
   dim3 grid(pairs, ksplit);
@@ -230,7 +416,7 @@ extern "C" size_t stv_gram_partials_bytes(int n_pixels, int channels) {
   return (size_t)stv_gram_ksplit(n_pixels, channels) * channels * channels * sizeof(float);
 }
 
-extern "C" int stv_gram_loss_parts(int channels) { return ceil_div(channels * channels, 64); }
+extern "C" int stv_gram_loss_parts(int channels) { return ceil_div(channels * channels, FIN_E); }
 
 extern "C" int stv_gram_partial(const void* F, float* partials, int n_pixels, int C, int dtype,
                                 void* stream) {

@@ -1,0 +1,415 @@
+// L-BFGS step in "dot-product space": the same update as torch.optim.LBFGS.step
+// (max_iter = 1, no line search; see optim.hip for the operation-ordered form)
+// but with the history read exactly twice per step instead of through 2m
+// dependent vector passes.
+//
+// The two-loop recursion only ever needs inner products between the history
+// vectors {s_i}, {y_i} and the gradient g.  With q = -g - sum_j alpha_j y_j:
+//     alpha_i = rho_i * (s_i . q) = rho_i * ( -(s_i.g) - sum_{j>i} alpha_j (s_i.y_j) )
+//     r = H q + sum_j (alpha_j - beta_j) s_j
+//     beta_i = rho_i * (y_i . r)  -> needs (y_i.g), (y_i.y_j), (y_i.s_j)
+// so we keep the S x S tables SY[i][j] = s_i.y_j and YY[i][j] = y_i.y_j across
+// steps (a pushed pair installs one row/column), and per step
+//   pass A : one sweep over the 2m history vectors + g computes every new dot
+//            product (5 per pair + 7 scalars) as per-wave partial sums;
+//   reduce : fixed-order summation of the partials (deterministic);
+//   solve  : one workgroup runs torch's scalar control flow and the recursion on
+//            coefficients (in double) and emits d = cg*g + sum cs_j s_j + cy_j y_j;
+//   pass B : second sweep forms d, applies x += t*d and prev_g = g.
+// HBM traffic per step: (4m + 8) vectors instead of ~(8m) with 2m+4 launches.
+#include "stv_common.h"
+
+namespace {
+
+constexpr int MAX_HIST = 128;
+constexpr int MAX_S = MAX_HIST + 1;
+constexpr int NSCAL = 8;   // gmax, |g|_1, g.g, g.s_c, g.y_c, s_c.y_c, y_c.y_c, (spare)
+
+struct CState {
+  int n_iter, hist_len, head, skip, no_update, pushed, steps_seen, pad0;
+  float t, H_diag, gtd, gmax, ys, yy, cg, pad1;
+  float ro[MAX_S];   // by ring slot
+  float cs[MAX_S];   // direction coefficients by ring slot
+  float cy[MAX_S];
+};
+
+struct CWs {
+  float* d;
+  float* prev_g;
+  float* S;
+  float* Y;
+  float* SY;      // [S][S] by ring slot
+  float* YY;      // [S][S]
+  double* dots;   // [5*MAX_HIST + NSCAL]
+  float* part;    // [5*hist + NSCAL][nparts]
+};
+
+__host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+inline int tile_floats(size_t n) {   // elements per workgroup tile: keep >= 512 workgroups when possible
+  if (n >= (size_t)4096 * 512) return 4096;
+  if (n >= (size_t)2048 * 512) return 2048;
+  return 1024;
+}
+
+inline CWs carve(void* workspace, size_t n, int hist, int nparts) {
+  const size_t nn = align_up(n, 4096);
+  const int S = hist + 1;
+  float* p = static_cast<float*>(workspace);
+  CWs w;
+  w.d = p; p += nn;
+  w.prev_g = p; p += nn;
+  w.S = p; p += nn * S;
+  w.Y = p; p += nn * S;
+  w.SY = p; p += align_up((size_t)S * S, 64);
+  w.YY = p; p += align_up((size_t)S * S, 64);
+  w.dots = reinterpret_cast<double*>(p); p += 2 * align_up(5 * (size_t)MAX_HIST + NSCAL, 64);
+  w.part = p;
+  (void)nparts;
+  return w;
+}
+
+__device__ __forceinline__ f32x4 ld4_guard(const float* __restrict__ p, size_t idx, size_t n) {
+  if (idx + 3 < n) return *reinterpret_cast<const f32x4*>(p + idx);
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (idx < n) v[0] = p[idx];
+  if (idx + 1 < n) v[1] = p[idx + 1];
+  if (idx + 2 < n) v[2] = p[idx + 2];
+  return v;
+}
+__device__ __forceinline__ float dot4(const f32x4& a, const f32x4& b) {
+  return fmaf(a[0], b[0], fmaf(a[1], b[1], fmaf(a[2], b[2], a[3] * b[3])));
+}
+
+// ---- pass A ---------------------------------------------------------------------------------
+template <int U>
+__global__ __launch_bounds__(256) void pass_a_kernel(const float* __restrict__ g, const CState* st, CWs w,
+                                                     size_t n, size_t nn, int hist, int nparts) {
+  const int S = hist + 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t base = (size_t)blockIdx.x * (256 * 4 * U);
+  const float t = st->t;
+  const int m = st->hist_len, head = st->head;
+  const int cslot = (head + m) % S;
+  float* __restrict__ yc = w.Y + (size_t)cslot * nn;
+  float* __restrict__ sc = w.S + (size_t)cslot * nn;
+  f32x4 gv[U], sv[U], yv[U];
+  float gmax = 0.f, gl1 = 0.f, gg = 0.f, gs = 0.f, gy = 0.f, sy = 0.f, yy = 0.f;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const size_t idx = base + (size_t)(u * 256 + tid) * 4;
+    gv[u] = ld4_guard(g, idx, n);
+    const f32x4 pg = *reinterpret_cast<const f32x4*>(w.prev_g + idx);   // nn-padded, zero tail
+    const f32x4 dv = *reinterpret_cast<const f32x4*>(w.d + idx);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      yv[u][e] = gv[u][e] - pg[e];
+      sv[u][e] = dv[e] * t;
+      gmax = fmaxf(gmax, fabsf(gv[u][e]));
+      gl1 += fabsf(gv[u][e]);
+    }
+    *reinterpret_cast<f32x4*>(yc + idx) = yv[u];
+    *reinterpret_cast<f32x4*>(sc + idx) = sv[u];
+    gg += dot4(gv[u], gv[u]);
+    gs += dot4(gv[u], sv[u]);
+    gy += dot4(gv[u], yv[u]);
+    sy += dot4(sv[u], yv[u]);
+    yy += dot4(yv[u], yv[u]);
+  }
+  const int p = blockIdx.x * 4 + wave;
+  for (int jj = 0; jj < m; ++jj) {
+    const int slot = (head + jj) % S;
+    const float* __restrict__ sj = w.S + (size_t)slot * nn;
+    const float* __restrict__ yj = w.Y + (size_t)slot * nn;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t idx = base + (size_t)(u * 256 + tid) * 4;
+      const f32x4 s4 = *reinterpret_cast<const f32x4*>(sj + idx);
+      const f32x4 y4 = *reinterpret_cast<const f32x4*>(yj + idx);
+      a0 += dot4(s4, gv[u]);   // s_j . g
+      a1 += dot4(y4, gv[u]);   // y_j . g
+      a2 += dot4(s4, yv[u]);   // s_j . y_c
+      a3 += dot4(y4, sv[u]);   // y_j . s_c
+      a4 += dot4(y4, yv[u]);   // y_j . y_c
+    }
+    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3); a4 = wave_sum(a4);
+    if (lane == 0) {
+      float* o = w.part + (size_t)(jj * 5) * nparts + p;
+      o[0] = a0; o[(size_t)nparts] = a1; o[(size_t)2 * nparts] = a2; o[(size_t)3 * nparts] = a3;
+      o[(size_t)4 * nparts] = a4;
+    }
+  }
+  gmax = wave_max(gmax);
+  gl1 = wave_sum(gl1); gg = wave_sum(gg); gs = wave_sum(gs); gy = wave_sum(gy); sy = wave_sum(sy); yy = wave_sum(yy);
+  if (lane == 0) {
+    float* o = w.part + (size_t)(5 * hist) * nparts + p;
+    o[0] = gmax; o[(size_t)nparts] = gl1; o[(size_t)2 * nparts] = gg; o[(size_t)3 * nparts] = gs;
+    o[(size_t)4 * nparts] = gy; o[(size_t)5 * nparts] = sy; o[(size_t)6 * nparts] = yy;
+  }
+}
+
+// ---- fixed-order reduction of the partials: one workgroup per dot product ----------------------
+__global__ __launch_bounds__(256) void reduce_kernel(const CState* st, CWs w, int hist, int nparts) {
+  __shared__ double red[256];
+  const int m = st->hist_len;
+  int dot = blockIdx.x;                       // [0, 5*m) history dots, then NSCAL scalars
+  const bool scalar = dot >= 5 * m;
+  if (scalar) dot = 5 * hist + (dot - 5 * m);
+  if (dot >= 5 * hist + NSCAL) return;
+  const float* __restrict__ src = w.part + (size_t)dot * nparts;
+  const bool is_max = dot == 5 * hist;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) {
+    const double v = (double)src[i];
+    acc = is_max ? fmax(acc, v) : acc + v;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s)
+      red[threadIdx.x] = is_max ? fmax(red[threadIdx.x], red[threadIdx.x + s]) : red[threadIdx.x] + red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) w.dots[scalar ? 5 * MAX_HIST + (dot - 5 * hist) : dot] = red[0];
+}
+
+// ---- control flow + recursion on coefficients ---------------------------------------------------
+__global__ __launch_bounds__(256) void solve_kernel(CState* st, CWs w, int hist, float lr, float tol_grad,
+                                                    float tol_change) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int S = hist + 1;
+  float* sSY = reinterpret_cast<float*>(smem_raw);       // [m][m] logical order
+  float* sYY = sSY + (size_t)hist * hist;
+  __shared__ int sh_skip, sh_pushed, sh_m, sh_head, sh_cslot, sh_mold;
+  __shared__ double sh_gs[MAX_S], sh_gy[MAX_S];
+  const int tid = threadIdx.x;
+  const double* D = w.dots;
+  const double* SC = w.dots + 5 * MAX_HIST;
+  const double gmax = SC[0], gl1 = SC[1], gg = SC[2], gsc = SC[3], gyc = SC[4], ys = SC[5], yy = SC[6];
+
+  if (tid == 0) {
+    st->steps_seen += 1;
+    st->gmax = (float)gmax;
+    st->no_update = 0;
+    st->pushed = 0;
+    const int skip = ((float)gmax <= tol_grad) ? 1 : 0;   // opt_cond: leave every piece of state untouched
+    st->skip = skip;
+    int pushed = 0;
+    const int m_old = st->hist_len;
+    const int cslot = (st->head + m_old) % S;
+    if (!skip) {
+      st->n_iter += 1;
+      if (st->n_iter == 1) {
+        st->hist_len = 0;
+        st->head = 0;
+        st->H_diag = 1.0f;
+      } else {
+        st->ys = (float)ys;
+        st->yy = (float)yy;
+        if ((float)ys > 1e-10f) {
+          pushed = 1;
+          if (st->hist_len == hist) st->head = (st->head + 1) % S;
+          else st->hist_len += 1;
+          st->ro[cslot] = 1.0f / (float)ys;
+          st->H_diag = (float)ys / (float)yy;
+        }
+      }
+      if (st->n_iter == 1) {
+        const float inv = 1.0f / (float)gl1;
+        st->t = ((inv < 1.0f) ? inv : 1.0f) * lr;
+      } else {
+        st->t = lr;
+      }
+      st->pushed = pushed;
+    }
+    sh_skip = skip; sh_pushed = pushed; sh_m = st->hist_len; sh_head = st->head; sh_cslot = cslot;
+    sh_mold = (st->n_iter == 1) ? 0 : m_old;
+  }
+  __syncthreads();
+  if (sh_skip) return;
+  const int m = sh_m, head = sh_head, cslot = sh_cslot, m_old = sh_mold;
+  const int old_head = (sh_pushed && m_old == hist) ? (head + S - 1) % S : head;
+
+  // install the pushed pair's row/column: old logical index jj sat in slot (old_head + jj) % S
+  if (sh_pushed) {
+    for (int jj = tid; jj < m_old; jj += 256) {
+      const int slot = (old_head + jj) % S;
+      const float s_j_yc = (float)D[jj * 5 + 2], y_j_sc = (float)D[jj * 5 + 3], y_j_yc = (float)D[jj * 5 + 4];
+      w.SY[(size_t)slot * S + cslot] = s_j_yc;     // s_j . y_c
+      w.SY[(size_t)cslot * S + slot] = y_j_sc;     // s_c . y_j
+      w.YY[(size_t)slot * S + cslot] = y_j_yc;
+      w.YY[(size_t)cslot * S + slot] = y_j_yc;
+    }
+    if (tid == 0) {
+      w.SY[(size_t)cslot * S + cslot] = (float)ys;
+      w.YY[(size_t)cslot * S + cslot] = (float)yy;
+    }
+  }
+  // g-dots in (new) logical order; the pushed pair is the newest logical index m-1
+  for (int i = tid; i < m; i += 256) {
+    const int slot = (head + i) % S;
+    if (sh_pushed && slot == cslot) {
+      sh_gs[i] = gsc;
+      sh_gy[i] = gyc;
+    } else {
+      const int jj = (slot - old_head + S) % S;     // its index during pass A
+      sh_gs[i] = D[jj * 5 + 0];
+      sh_gy[i] = D[jj * 5 + 1];
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int e = tid; e < m * m; e += 256) {
+    const int i = e / m, j = e - i * m;
+    const size_t src = (size_t)((head + i) % S) * S + (head + j) % S;
+    sSY[i * hist + j] = w.SY[src];
+    sYY[i * hist + j] = w.YY[src];
+  }
+  __syncthreads();
+  if (tid >= 64) return;
+
+  // ---- one wave: torch's two-loop on coefficients; lane owns logical indices lane, lane+64 ----
+  const int lane = tid;
+  const int j0 = lane, j1 = lane + 64;
+  double cy0 = 0.0, cy1 = 0.0, cs0 = 0.0, cs1 = 0.0, al0 = 0.0, al1 = 0.0;
+  double cg = -1.0;
+  for (int i = m - 1; i >= 0; --i) {
+    double part = 0.0;
+    if (j0 > i && j0 < m) part += cy0 * (double)sSY[i * hist + j0];
+    if (j1 > i && j1 < m) part += cy1 * (double)sSY[i * hist + j1];
+    part = wave_sum_d(part);
+    const double rho = (double)st->ro[(head + i) % S];
+    const double al = (double)(float)((float)(cg * sh_gs[i] + part) * (float)rho);   // fp32 like torch's al[i]
+    if (i == j0) { al0 = al; cy0 = -al; }
+    if (i == j1) { al1 = al; cy1 = -al; }
+  }
+  const double H = (double)st->H_diag;
+  cg *= H; cy0 *= H; cy1 *= H;
+  for (int i = 0; i < m; ++i) {
+    double part = 0.0;
+    if (j0 < m) part += cy0 * (double)sYY[i * hist + j0];
+    if (j1 < m) part += cy1 * (double)sYY[i * hist + j1];
+    if (j0 < i) part += cs0 * (double)sSY[j0 * hist + i];
+    if (j1 < i) part += cs1 * (double)sSY[j1 * hist + i];
+    part = wave_sum_d(part);
+    const double rho = (double)st->ro[(head + i) % S];
+    const double be = (double)(float)((float)(cg * sh_gy[i] + part) * (float)rho);
+    if (i == j0) cs0 = (double)(float)((float)al0 - (float)be);
+    if (i == j1) cs1 = (double)(float)((float)al1 - (float)be);
+  }
+  double gtd = 0.0;
+  if (j0 < m) gtd += cy0 * sh_gy[j0] + cs0 * sh_gs[j0];
+  if (j1 < m) gtd += cy1 * sh_gy[j1] + cs1 * sh_gs[j1];
+  gtd = wave_sum_d(gtd) + cg * gg;
+  if (j0 < m) { st->cs[(head + j0) % S] = (float)cs0; st->cy[(head + j0) % S] = (float)cy0; }
+  if (j1 < m) { st->cs[(head + j1) % S] = (float)cs1; st->cy[(head + j1) % S] = (float)cy1; }
+  if (lane == 0) {
+    st->cg = (float)cg;
+    st->gtd = (float)gtd;
+    st->no_update = ((float)gtd > -tol_change) ? 1 : 0;
+  }
+}
+
+// ---- pass B: form the direction, move x, remember g ------------------------------------------------
+template <int U>
+__global__ __launch_bounds__(256) void pass_b_kernel(float* __restrict__ x, const float* __restrict__ g,
+                                                     const CState* st, CWs w, size_t n, size_t nn, int hist) {
+  if (st->skip) return;
+  const int S = hist + 1;
+  const int tid = threadIdx.x;
+  const size_t base = (size_t)blockIdx.x * (256 * 4 * U);
+  const int m = st->hist_len, head = st->head;
+  const float cg = st->cg, t = st->t;
+  const bool move = st->no_update == 0;
+  f32x4 acc[U], gv[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const size_t idx = base + (size_t)(u * 256 + tid) * 4;
+    gv[u] = ld4_guard(g, idx, n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[u][e] = cg * gv[u][e];
+  }
+  for (int jj = 0; jj < m; ++jj) {
+    const int slot = (head + jj) % S;
+    const float cs = st->cs[slot], cy = st->cy[slot];
+    const float* __restrict__ sj = w.S + (size_t)slot * nn;
+    const float* __restrict__ yj = w.Y + (size_t)slot * nn;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t idx = base + (size_t)(u * 256 + tid) * 4;
+      const f32x4 s4 = *reinterpret_cast<const f32x4*>(sj + idx);
+      const f32x4 y4 = *reinterpret_cast<const f32x4*>(yj + idx);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[u][e] = fmaf(cs, s4[e], fmaf(cy, y4[e], acc[u][e]));
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const size_t idx = base + (size_t)(u * 256 + tid) * 4;
+    *reinterpret_cast<f32x4*>(w.d + idx) = acc[u];
+    *reinterpret_cast<f32x4*>(w.prev_g + idx) = gv[u];
+    if (move) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (idx + e < n) x[idx + e] = fmaf(t, acc[u][e], x[idx + e]);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" size_t stv_lbfgsc_state_bytes(int history) {
+  (void)history;
+  return sizeof(CState);
+}
+
+extern "C" size_t stv_lbfgsc_workspace_bytes(size_t n, int history) {
+  const size_t nn = align_up(n, 4096);
+  const int S = history + 1;
+  const int tile = tile_floats(n);
+  const size_t nparts = (nn / tile) * 4;
+  size_t floats = nn * (2 + 2 * (size_t)S) + 2 * align_up((size_t)S * S, 64) +
+                  2 * 2 * align_up(5 * (size_t)MAX_HIST + NSCAL, 64) + (5 * (size_t)history + NSCAL) * nparts + 64;
+  return floats * sizeof(float);
+}
+
+extern "C" int stv_lbfgsc_step(float* x, const float* grad, void* state, void* workspace, size_t n, int history,
+                               int m_max, float lr, float tol_grad, float tol_change, void* stream) {
+  if (!x || !grad || !state || !workspace || n == 0) return STV_ERR_ARG;
+  if (history < 1 || history > MAX_HIST) return STV_ERR_ARG;
+  if (m_max < 0) m_max = 0;
+  if (m_max > history) m_max = history;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  CState* s = static_cast<CState*>(state);
+  const size_t nn = align_up(n, 4096);
+  const int tile = tile_floats(n);
+  const int ntiles = (int)(nn / tile);
+  const int nparts = ntiles * 4;
+  const CWs w = carve(workspace, n, history, nparts);
+  const size_t lds = 2 * (size_t)history * history * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            2 * MAX_HIST * MAX_HIST * (int)sizeof(float)) != hipSuccess)
+      return STV_ERR_LAUNCH;
+    attr = true;
+  }
+  if (tile == 4096)
+    hipLaunchKernelGGL(pass_a_kernel<4>, dim3(ntiles), dim3(256), 0, st, grad, s, w, n, nn, history, nparts);
+  else if (tile == 2048)
+    hipLaunchKernelGGL(pass_a_kernel<2>, dim3(ntiles), dim3(256), 0, st, grad, s, w, n, nn, history, nparts);
+  else
+    hipLaunchKernelGGL(pass_a_kernel<1>, dim3(ntiles), dim3(256), 0, st, grad, s, w, n, nn, history, nparts);
+  hipLaunchKernelGGL(reduce_kernel, dim3(5 * m_max + NSCAL), dim3(256), 0, st, s, w, history, nparts);
+  hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(256), lds, st, s, w, history, lr, tol_grad, tol_change);
+  if (tile == 4096)
+    hipLaunchKernelGGL(pass_b_kernel<4>, dim3(ntiles), dim3(256), 0, st, x, grad, s, w, n, nn, history);
+  else if (tile == 2048)
+    hipLaunchKernelGGL(pass_b_kernel<2>, dim3(ntiles), dim3(256), 0, st, x, grad, s, w, n, nn, history);
+  else
+    hipLaunchKernelGGL(pass_b_kernel<1>, dim3(ntiles), dim3(256), 0, st, x, grad, s, w, n, nn, history);
+  STV_CHECK_LAUNCH();
+  return STV_OK;
+}

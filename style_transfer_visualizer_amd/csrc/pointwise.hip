@@ -172,9 +172,21 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const T* __restrict__ x, 
 template <typename T>
 __global__ __launch_bounds__(256) void content_loss_kernel(const T* __restrict__ f, const T* __restrict__ t,
                                                            float* __restrict__ part, size_t n) {
+  constexpr int kVec = elem_traits<T>::kVec;
   __shared__ float red[4];
   float s = 0.0f;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+  const size_t nv = n / kVec;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
+    float a[kVec], b[kVec];
+    unpack16<T>(reinterpret_cast<const u32x4*>(f)[i], a);
+    unpack16<T>(reinterpret_cast<const u32x4*>(t)[i], b);
+#pragma unroll
+    for (int e = 0; e < kVec; ++e) {
+      const float d = a[e] - b[e];
+      s = fmaf(d, d, s);
+    }
+  }
+  for (size_t i = nv * kVec + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const float d = elem_traits<T>::load(f + i) - elem_traits<T>::load(t + i);
     s = fmaf(d, d, s);
   }
@@ -185,9 +197,20 @@ template <typename T>
 __global__ __launch_bounds__(256) void content_grad_kernel(const T* __restrict__ f, const T* __restrict__ t,
                                                            T* __restrict__ df, size_t n, float coef,
                                                            const float* __restrict__ coef_dev, int flags) {
+  constexpr int kVec = elem_traits<T>::kVec;
   const float k = coef * (coef_dev ? *coef_dev : 1.0f) * (2.0f / (float)n);
   const bool accum = (flags & STV_ACCUM) != 0;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+  const size_t nv = n / kVec;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
+    float a[kVec], b[kVec], o[kVec];
+    unpack16<T>(reinterpret_cast<const u32x4*>(f)[i], a);
+    unpack16<T>(reinterpret_cast<const u32x4*>(t)[i], b);
+    if (accum) unpack16<T>(reinterpret_cast<const u32x4*>(df)[i], o);
+#pragma unroll
+    for (int e = 0; e < kVec; ++e) o[e] = k * (a[e] - b[e]) + (accum ? o[e] : 0.0f);
+    reinterpret_cast<u32x4*>(df)[i] = pack16<T>(o);
+  }
+  for (size_t i = nv * kVec + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     float g = k * (elem_traits<T>::load(f + i) - elem_traits<T>::load(t + i));
     if (accum) g += elem_traits<T>::load(df + i);
     elem_traits<T>::store(df + i, g);
@@ -195,26 +218,40 @@ __global__ __launch_bounds__(256) void content_grad_kernel(const T* __restrict__
 }
 
 // ------------------------------------------------------------ score combine
-// One wave.  losses[k] = scale[k] * sum(parts[off..off+cnt)); then the
-// reference's sequential fp32 stack().sum() per kind and the weighted total.
-__global__ void loss_combine_kernel(const float* __restrict__ parts, const int32_t* __restrict__ table,
-                                    const float* __restrict__ scale, int n_terms, float style_w,
-                                    float content_w, float* __restrict__ losses, float* __restrict__ scores) {
-  const int lane = threadIdx.x;
+// One workgroup of 1024 threads.  losses[k] = scale[k] * sum(parts[off..off+cnt)) with a
+// fixed summation tree (deterministic); then the reference's sequential fp32
+// stack().sum() per kind and the weighted total.
+__global__ __launch_bounds__(1024) void loss_combine_kernel(const float* __restrict__ parts,
+                                                            const int32_t* __restrict__ table,
+                                                            const float* __restrict__ scale, int n_terms,
+                                                            float style_w, float content_w,
+                                                            float* __restrict__ losses, float* __restrict__ scores) {
+  __shared__ double red[16];
+  __shared__ float term[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int k = 0; k < n_terms; ++k) {
     const int off = table[3 * k], cnt = table[3 * k + 1];
     double s = 0.0;
-    for (int i = lane; i < cnt; i += 64) s += (double)parts[off + i];
+    for (int i = tid; i < cnt; i += 1024) s += (double)parts[off + i];
     s = wave_sum_d(s);
-    if (lane == 0) losses[k] = (float)(s * (double)scale[k]);
+    __syncthreads();
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (tid == 0) {
+      double tot = 0.0;
+      for (int w = 0; w < 16; ++w) tot += red[w];
+      const float v = (float)(tot * (double)scale[k]);
+      losses[k] = v;
+      if (k < 64) term[k] = v;
+    }
   }
-  __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
-  if (lane == 0) {
+  if (tid == 0) {
     float style = 0.0f, content = 0.0f;
     for (int k = 0; k < n_terms; ++k) {
-      if (table[3 * k + 2] == 0) style += losses[k];
-      else content += losses[k];
+      const float v = (k < 64) ? term[k] : losses[k];
+      if (table[3 * k + 2] == 0) style += v;
+      else content += v;
     }
     const float total = style_w * style + content_w * content;
     scores[0] = style;
@@ -321,11 +358,11 @@ extern "C" int stv_content_grad(const void* F, const void* target, void* dF, siz
   if (!F || !target || !dF || n == 0) return STV_ERR_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dtype == STV_F32)
-    hipLaunchKernelGGL(content_grad_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st,
+    hipLaunchKernelGGL(content_grad_kernel<float>, dim3(grid_for(n / 4 + 1)), dim3(256), 0, st,
                        static_cast<const float*>(F), static_cast<const float*>(target),
                        static_cast<float*>(dF), n, coef, coef_dev, flags);
   else if (dtype == STV_BF16)
-    hipLaunchKernelGGL(content_grad_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st,
+    hipLaunchKernelGGL(content_grad_kernel<bf16_t>, dim3(grid_for(n / 8 + 1)), dim3(256), 0, st,
                        static_cast<const bf16_t*>(F), static_cast<const bf16_t*>(target),
                        static_cast<bf16_t*>(dF), n, coef, coef_dev, flags);
   else
@@ -337,7 +374,7 @@ extern "C" int stv_content_grad(const void* F, const void* target, void* dF, siz
 extern "C" int stv_loss_combine(const float* parts, const int32_t* table, const float* scale, int n_terms,
                                 float style_w, float content_w, float* losses, float* scores, void* stream) {
   if (!parts || !table || !scale || !losses || !scores || n_terms < 0) return STV_ERR_ARG;
-  hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), parts,
+  hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), parts,
                      table, scale, n_terms, style_w, content_w, losses, scores);
   STV_CHECK_LAUNCH();
   return STV_OK;

@@ -202,19 +202,26 @@ def loss_combine(parts: torch.Tensor, table: torch.Tensor, scale: torch.Tensor, 
 
 # ---- optimizers ---------------------------------------------------------------
 
-def lbfgs_alloc(n: int, history: int, device: torch.device) -> tuple[torch.Tensor, torch.Tensor]:
+def lbfgs_alloc(n: int, history: int, device: torch.device, *, compact: bool = False,
+                ) -> tuple[torch.Tensor, torch.Tensor]:
+    """Zeroed device state block + workspace for ``lbfgs_step`` (``compact`` selects the layout)."""
     lib = _lib.load()
-    state = torch.zeros(lib.stv_lbfgs_state_bytes(history), dtype=torch.uint8, device=device)
-    ws_bytes = lib.stv_lbfgs_workspace_bytes(n, history)
+    if compact:
+        st_bytes, ws_bytes = lib.stv_lbfgsc_state_bytes(history), lib.stv_lbfgsc_workspace_bytes(n, history)
+    else:
+        st_bytes, ws_bytes = lib.stv_lbfgs_state_bytes(history), lib.stv_lbfgs_workspace_bytes(n, history)
+    state = torch.zeros(st_bytes, dtype=torch.uint8, device=device)
     work = torch.zeros((ws_bytes + 3) // 4, dtype=torch.float32, device=device)
     return state, work
 
 
 def lbfgs_step(x: torch.Tensor, grad: torch.Tensor, state: torch.Tensor, work: torch.Tensor, history: int,
-               m_max: int, lr: float, tol_grad: float = 1e-7, tol_change: float = 1e-9) -> None:
+               m_max: int, lr: float, tol_grad: float = 1e-7, tol_change: float = 1e-9, *,
+               compact: bool = False) -> None:
     lib = _lib.load()
-    _lib.check(lib.stv_lbfgs_step(_ptr(x), _ptr(grad), _ptr(state), _ptr(work), x.numel(), history, m_max, lr,
-                                  tol_grad, tol_change, _stream()), "stv_lbfgs_step")
+    fn = lib.stv_lbfgsc_step if compact else lib.stv_lbfgs_step
+    _lib.check(fn(_ptr(x), _ptr(grad), _ptr(state), _ptr(work), x.numel(), history, m_max, lr,
+                  tol_grad, tol_change, _stream()), "stv_lbfgsc_step" if compact else "stv_lbfgs_step")
 
 
 def adam_step(x: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, step: int,

@@ -8,6 +8,7 @@ and branch stays on the GPU (``stv_lbfgs_step``), so ``step`` never syncs.
 """
 from __future__ import annotations
 
+import os
 from collections.abc import Callable
 
 import torch
@@ -49,7 +50,10 @@ class HipLBFGS(torch.optim.Optimizer):
                         tolerance_change=tolerance_change, history_size=history_size, line_search_fn=None)
         super().__init__([p], defaults)
         self._p = p
-        self._dev_state, self._work = ops.lbfgs_alloc(p.numel(), history_size, p.device)
+        # "compact": history read twice per step (inner-product tables); "twoloop": torch's
+        # operation order, 2m dependent passes.  Same state machine, rounding-level differences.
+        self._compact = os.environ.get("STV_LBFGS", "compact") != "twoloop"
+        self._dev_state, self._work = ops.lbfgs_alloc(p.numel(), history_size, p.device, compact=self._compact)
         self._steps = 0
 
     @torch.no_grad()
@@ -64,7 +68,7 @@ class HipLBFGS(torch.optim.Optimizer):
             grad = grad.contiguous()
         ops.lbfgs_step(self._p, grad, self._dev_state, self._work, g["history_size"],
                        min(self._steps, g["history_size"]), float(g["lr"]), g["tolerance_grad"],
-                       g["tolerance_change"])
+                       g["tolerance_change"], compact=self._compact)
         self._steps += 1
         return loss
 
@@ -72,9 +76,10 @@ class HipLBFGS(torch.optim.Optimizer):
         """Debug/test view of the device state block (this call synchronises)."""
         raw = self._dev_state.cpu()
         ints, flts = raw.view(torch.int32), raw.view(torch.float32)
+        f0 = 8 if self._compact else 6      # first float field of the state struct
         return {"n_iter": int(ints[0]), "hist_len": int(ints[1]), "head": int(ints[2]), "skip": int(ints[3]),
-                "no_update": int(ints[4]), "steps_seen": int(ints[5]), "t": float(flts[6]),
-                "H_diag": float(flts[7]), "gtd": float(flts[8]), "gmax": float(flts[9])}
+                "no_update": int(ints[4]), "t": float(flts[f0]), "H_diag": float(flts[f0 + 1]),
+                "gtd": float(flts[f0 + 2]), "gmax": float(flts[f0 + 3])}
 
 
 class HipAdam(torch.optim.Optimizer):

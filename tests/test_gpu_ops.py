@@ -243,14 +243,15 @@ def _quartic(n, seed):
     return f
 
 
+@pytest.mark.parametrize("compact", [False, True])
 @pytest.mark.parametrize("history", [4, 100])
-def test_lbfgs_step_matches_oracle(history):
+def test_lbfgs_step_matches_oracle(history, compact):
     n, steps = 20000, 14
     f = _quartic(n, 81)
     x_ref = torch.zeros(n)
     ref = optim_ref.LbfgsRef(x_ref, lr=1.0, history_size=history)
     x = torch.zeros(n, device=DEV)
-    state, work = ops.lbfgs_alloc(n, history, torch.device(DEV))
+    state, work = ops.lbfgs_alloc(n, history, torch.device(DEV), compact=compact)
     for step in range(steps):
         def closure():
             with torch.enable_grad():
@@ -262,7 +263,7 @@ def test_lbfgs_step_matches_oracle(history):
         with torch.enable_grad():
             xg = x.detach().cpu().clone().requires_grad_(True)
             f(xg).backward()
-        ops.lbfgs_step(x, xg.grad.to(DEV), state, work, history, min(step, history), 1.0)
+        ops.lbfgs_step(x, xg.grad.to(DEV), state, work, history, min(step, history), 1.0, compact=compact)
         err = float((x.cpu() - x_ref).abs().max()) / float(x_ref.abs().max())
         assert err < 2e-4, f"step {step + 1}: x diverged from the oracle by {err:.3e}"
     st = state.cpu().view(torch.int32)
@@ -270,17 +271,18 @@ def test_lbfgs_step_matches_oracle(history):
     assert int(st[1]) == len(ref.old_dirs)
 
 
-def test_lbfgs_early_return_and_no_descent():
-    n = 4096
+@pytest.mark.parametrize("compact", [False, True])
+def test_lbfgs_early_return_and_no_descent(compact):
+    n = 4099                                            # not a multiple of the vector width
     x = torch.ones(n, device=DEV)
-    state, work = ops.lbfgs_alloc(n, 100, torch.device(DEV))
+    state, work = ops.lbfgs_alloc(n, 100, torch.device(DEV), compact=compact)
     tiny = torch.full((n,), 5e-8, device=DEV)           # |g|max <= 1e-7 -> return before any update
-    ops.lbfgs_step(x, tiny, state, work, 100, 0, 1.0)
+    ops.lbfgs_step(x, tiny, state, work, 100, 0, 1.0, compact=compact)
     st = state.cpu().view(torch.int32)
     assert int(st[0]) == 0 and int(st[3]) == 1
     assert torch.equal(x.cpu(), torch.ones(n))
     g = torch.full((n,), 1.0, device=DEV)
-    ops.lbfgs_step(x, g, state, work, 100, 0, 1.0)       # first real step: t = min(1, 1/|g|_1)
+    ops.lbfgs_step(x, g, state, work, 100, 0, 1.0, compact=compact)   # first real step: t = min(1, 1/|g|_1)
     st = state.cpu().view(torch.int32)
     assert int(st[0]) == 1 and int(st[3]) == 0
     np.testing.assert_allclose(x.cpu().numpy(), 1.0 - 1.0 / n, rtol=1e-6)
