@@ -97,6 +97,126 @@ __global__ __launch_bounds__(256) void conv_first_dgrad_kernel(
   }
 }
 
+// ---- fast path for the VGG shape (cin = 3, cout = 64): 16x16 pixel tiles ---------------------------
+// fwd : the 18x18x3 fp32 halo tile sits in LDS; one lane = one pixel x all 64 output channels.
+//       The weight index is wave-uniform, so weights come through the scalar cache as SGPR
+//       operands of v_fmac: exactly 27*64 FMAs per pixel and 27 conflict-free LDS reads.  Output
+//       rows are transposed through LDS so each wave store is 1 KiB of contiguous NHWC bytes.
+// dgrad: the 18x18x64 dy halo tile sits in LDS (pixel pitch padded to 16 B past a power of two);
+//       one lane = one pixel x 3 input channels, again with scalar weights.
+constexpr int FT = 16;            // tile edge
+constexpr int FH = FT + 2;        // halo edge
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv_first_fwd_c64(const float* __restrict__ x,
+                                                          const float* __restrict__ wt,   // [9][3][64]
+                                                          const float* __restrict__ bias, T* __restrict__ y,
+                                                          int H, int W) {
+  constexpr int CO = 64;
+  constexpr int OPB = CO * (int)sizeof(T);          // output bytes per pixel
+  constexpr int OPITCH = OPB + 16;
+  __shared__ __attribute__((aligned(16))) float xs[3][FH][FH + 1];
+  __shared__ __attribute__((aligned(16))) char os[256 * OPITCH];
+  const int tid = threadIdx.x;
+  const int tiles_x = (W + FT - 1) / FT;
+  const int x0 = (blockIdx.x % tiles_x) * FT, y0 = (blockIdx.x / tiles_x) * FT;
+  for (int i = tid; i < 3 * FH * FH; i += 256) {
+    const int c = i / (FH * FH), r = (i / FH) % FH, q = i % FH;
+    const int gy = y0 + r - 1, gx = x0 + q - 1;
+    xs[c][r][q] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? x[((size_t)c * H + gy) * W + gx] : 0.0f;
+  }
+  __syncthreads();
+  const int py = tid / FT, px = tid % FT;
+  float acc[CO];
+#pragma unroll
+  for (int n = 0; n < CO; ++n) acc[n] = bias ? bias[n] : 0.0f;
+  // 27 (tap, channel) steps, NOT unrolled: each step streams its 64 weights through SGPRs;
+  // unrolling would hoist all 1728 scalar loads and spill the scalar file
+#pragma unroll 1
+  for (int tc = 0; tc < 27; ++tc) {
+    const int tap = tc / 3, c = tc - tap * 3;
+    const float xv = xs[c][py + tap / 3][px + tap % 3];
+    const float* __restrict__ wp = wt + tc * CO;               // wave-uniform -> scalar loads
+#pragma unroll
+    for (int n = 0; n < CO; ++n) acc[n] = fmaf(xv, wp[n], acc[n]);
+  }
+  // own pixel row -> LDS, then the block stores whole contiguous rows
+  char* mine = os + tid * OPITCH;
+  constexpr int kVec = elem_traits<T>::kVec;
+#pragma unroll
+  for (int v = 0; v < CO / kVec; ++v) *reinterpret_cast<u32x4*>(mine + v * 16) = pack16<T>(acc + v * kVec);
+  __syncthreads();
+  constexpr int VPP = OPB / 16;                       // 16-byte vectors per pixel
+  for (int i = tid; i < 256 * VPP; i += 256) {
+    const int p = i / VPP, v = i % VPP;
+    const int gy = y0 + p / FT, gx = x0 + p % FT;
+    if (gy < H && gx < W)
+      *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(y) + ((size_t)gy * W + gx) * OPB + v * 16) =
+          *reinterpret_cast<const u32x4*>(os + p * OPITCH + v * 16);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv_first_dgrad_c64(const T* __restrict__ dy,
+                                                            const float* __restrict__ wd,   // [9][3][64], taps as read
+                                                            float* __restrict__ dx, int H, int W) {
+  constexpr int CO = 64;
+  constexpr int PB = CO * (int)sizeof(T);
+  constexpr int PITCH = PB + 16;
+  constexpr int kVec = elem_traits<T>::kVec;
+  constexpr int VPP = PB / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int tiles_x = (W + FT - 1) / FT;
+  const int x0 = (blockIdx.x % tiles_x) * FT, y0 = (blockIdx.x / tiles_x) * FT;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  for (int i = tid; i < FH * FH * VPP; i += 256) {
+    const int p = i / VPP, v = i % VPP;
+    const int gy = y0 + p / FH - 1, gx = x0 + p % FH - 1;
+    const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+    *reinterpret_cast<u32x4*>(smem + p * PITCH + v * 16) =
+        ok ? *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(dy) + ((size_t)gy * W + gx) * PB + v * 16)
+           : zero4;
+  }
+  __syncthreads();
+  const int py = tid / FT, px = tid % FT;
+  float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+  // dx[q] = sum_tap dy[q - off(tap)] w[tap]; with t' = 8 - tap the read offset is +off(t'), and wd is
+  // packed in that (already flipped) order
+#pragma unroll 1
+  for (int tap = 0; tap < 9; ++tap) {
+    const char* src = smem + ((py + tap / 3) * FH + (px + tap % 3)) * PITCH;
+    const float* __restrict__ wp = wd + tap * 3 * CO;          // wave-uniform -> scalar loads
+#pragma unroll 2
+    for (int v = 0; v < VPP; ++v) {
+      float g[kVec];
+      unpack16<T>(*reinterpret_cast<const u32x4*>(src + v * 16), g);
+#pragma unroll
+      for (int e = 0; e < kVec; ++e) {
+        a0 = fmaf(g[e], wp[0 * CO + v * kVec + e], a0);
+        a1 = fmaf(g[e], wp[1 * CO + v * kVec + e], a1);
+        a2 = fmaf(g[e], wp[2 * CO + v * kVec + e], a2);
+      }
+    }
+  }
+  const int gy = y0 + py, gx = x0 + px;
+  if (gy < H && gx < W) {
+    const size_t plane = (size_t)H * W, o = (size_t)gy * W + gx;
+    dx[o] = a0;
+    dx[plane + o] = a1;
+    dx[2 * plane + o] = a2;
+  }
+}
+
+// repack [9][64][3] -> [9][3][64] (fwd) or flipped taps (dgrad); tiny, run per call on the stream
+__global__ void repack_first_weights(const float* __restrict__ wf, float* __restrict__ wt, int flip) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 9 * 3 * 64) return;
+  const int n = i % 64, c = (i / 64) % 3, tap = i / 192;
+  const int src_tap = flip ? 8 - tap : tap;
+  wt[i] = wf[(src_tap * 64 + n) * 3 + c];
+}
+
 // slow generic variants (any cout): one thread per output element
 template <typename T>
 __global__ void conv_first_fwd_generic(const float* __restrict__ x, const float* __restrict__ wf,
@@ -145,9 +265,25 @@ inline int lanes_shift(int cout, int kvec) {
   return s;
 }
 
+// scratch for the repacked first-layer weights (2 x 1728 floats), allocated once per process
+float* first_scratch() {
+  static float* p = nullptr;
+  if (!p && hipMalloc(reinterpret_cast<void**>(&p), 2 * 1728 * sizeof(float)) != hipSuccess) p = nullptr;
+  return p;
+}
+
 template <typename T>
 int fwd_typed(const float* x, const float* wf, const float* bias, void* y, int H, int W, int cin,
               int cout, hipStream_t st) {
+  if (cin == 3 && cout == 64) {
+    float* wt = first_scratch();
+    if (!wt) return STV_ERR_ALLOC;
+    hipLaunchKernelGGL(repack_first_weights, dim3(7), dim3(256), 0, st, wf, wt, 0);
+    const int tiles = ceil_div(W, FT) * ceil_div(H, FT);
+    hipLaunchKernelGGL(conv_first_fwd_c64<T>, dim3(tiles), dim3(256), 0, st, x, wt, bias, static_cast<T*>(y), H, W);
+    STV_CHECK_LAUNCH();
+    return STV_OK;
+  }
   const int sh = lanes_shift(cout, elem_traits<T>::kVec);
   const size_t lds = (size_t)9 * cin * cout * sizeof(float);
   if (sh >= 0 && lds <= 64 * 1024) {
@@ -165,6 +301,25 @@ int fwd_typed(const float* x, const float* wf, const float* bias, void* y, int H
 template <typename T>
 int dgrad_typed(const void* dy, const float* wf, float* dx, int H, int W, int cin, int cout,
                 hipStream_t st) {
+  if (cin == 3 && cout == 64) {
+    float* wt = first_scratch();
+    if (!wt) return STV_ERR_ALLOC;
+    float* wd = wt + 1728;
+    hipLaunchKernelGGL(repack_first_weights, dim3(7), dim3(256), 0, st, wf, wd, 1);
+    const int tiles = ceil_div(W, FT) * ceil_div(H, FT);
+    const size_t lds = (size_t)FH * FH * (64 * sizeof(T) + 16);
+    static bool attr = false;
+    if (!attr) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_first_dgrad_c64<T>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return STV_ERR_LAUNCH;
+      attr = true;
+    }
+    hipLaunchKernelGGL(conv_first_dgrad_c64<T>, dim3(tiles), dim3(256), lds, st, static_cast<const T*>(dy), wd, dx,
+                       H, W);
+    STV_CHECK_LAUNCH();
+    return STV_OK;
+  }
   const int sh = lanes_shift(cout, elem_traits<T>::kVec);
   const size_t lds = (size_t)9 * cin * cout * sizeof(float);
   if (sh >= 0 && lds <= 64 * 1024 && cin <= kMaxCin) {

@@ -126,6 +126,40 @@ def test_trajectory_matches_reference(golden_case: GoldenCase, monkeypatch):
         np.testing.assert_allclose(out.detach().cpu().numpy(), xf, rtol=0, atol=ptol * np.abs(xf).max())
 
 
+def _decision_flips(model, oracle64, x64):
+    """Count ReLU-sign / max-pool-argmax decisions where the HIP activations disagree with the fp64
+    oracle, and the largest fp64 gap (relative to the layer's scale) among those positions."""
+    import torch.nn.functional as F
+    from style_transfer_visualizer_amd import ops
+    eng = next(iter(model._engines.values()))
+    acts = []
+    h = x64
+    last = max(n.layer for n in eng.sched.nodes) + 1
+    for li in range(min(last + 1, len(oracle64.program))):
+        h = ocm.run_layer(oracle64.program[li], h)
+        acts.append(h)
+    flips, worst = 0, 0.0
+    for nd in eng.sched.nodes:
+        if nd.kind in ("conv", "conv_first") and nd.dst.relu_fused:
+            z = acts[nd.layer]                                  # fp64 pre-activation
+            hip_on = ops.from_nhwc(nd.dst.act).cpu() > 0
+            diff = hip_on != (z > 0)
+            if diff.any():
+                flips += int(diff.sum())
+                worst = max(worst, float(z[diff].abs().max() / z.abs().max()))
+        if nd.kind == "pool":
+            src = acts[nd.layer - 1]
+            a_hip = ops.from_nhwc(nd.src.act).cpu().double()
+            v_ref, i_ref = F.max_pool2d(src, 2, 2, return_indices=True)
+            _, i_hip = F.max_pool2d(a_hip, 2, 2, return_indices=True)
+            diff = i_hip != i_ref
+            if diff.any():
+                flips += int(diff.sum())
+                alt = src.flatten(2).gather(2, i_hip.flatten(2)).reshape(v_ref.shape)   # fp64 value HIP picked
+                worst = max(worst, float((v_ref - alt)[diff].abs().max() / src.abs().max()))
+    return flips, worst
+
+
 @pytest.mark.parametrize("compact", [False, True])
 @pytest.mark.parametrize("name", ["mini_content_lbfgs", "mini_random_lbfgs_nonorm", "vgg19_content_lbfgs"])
 def test_every_step_matches_oracle_at_same_image(name, compact, monkeypatch):
@@ -166,7 +200,15 @@ def test_every_step_matches_oracle_at_same_image(name, compact, monkeypatch):
         g = x.grad.detach().cpu()
         err_hip = float((g.double() - g64).norm() / g64.norm())
         err_cpu = float((go.double() - g64).norm() / g64.norm())
-        assert err_hip <= max(3 * err_cpu, 2e-5), f"step {step + 1}: HIP {err_hip:.2e} vs CPU-fp32 {err_cpu:.2e}"
+        flips, worst_gap = _decision_flips(model, oracle64, xc.double())
+        if flips == 0:
+            assert err_hip <= max(3 * err_cpu, 2e-5), f"step {step + 1}: HIP {err_hip:.2e} vs CPU-fp32 {err_cpu:.2e}"
+        else:
+            # every differing ReLU / max-pool decision must be a genuine near-tie of the fp64 values
+            assert worst_gap < 1e-4, f"step {step + 1}: decision differs at a gap of {worst_gap:.2e} of the layer scale"
+            assert flips <= 8
+            err = (g.double() - g64).abs() / g64.abs().max()
+            assert float(err.median()) < 2e-5, f"step {step + 1}"
         twin.step(lambda: (t.cpu(), g))
         ops.lbfgs_step(x.detach(), x.grad, state, work, 100, min(step, 100), 1.0, compact=compact)
         drift = float((x.detach().cpu() - x_twin).abs().max() / x_twin.abs().max())
