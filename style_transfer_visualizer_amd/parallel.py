@@ -1,0 +1,77 @@
+"""Multi-GPU execution of the path: independent images, one process per GPU.
+
+The per-step path of one image does not shard usefully at 512^2/1024^2 (26
+halo exchanges per closure for ~1 ms of work), and a batch is
+NOT a batch dimension (``gram_matrix`` folds batch into channels, reference
+core_model.py:56-57).  So N GPUs run N independent content/style pairs -
+replicas of the single-image path with their own L-BFGS state - and the only
+collective is one all-gather of the finished images (RCCL over xGMI on GPUs,
+gloo in CPU tests).  No collective sits on the per-step data path.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend: str | None = None) -> tuple[int, int, int]:
+    """Initialise from the torchrun environment; returns (rank, local_rank, world_size)."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kwargs = {}
+        if backend == "nccl":
+            kwargs["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
+    return rank, local_rank, world
+
+
+def shard_items(n_items: int, rank: int, world: int) -> list[int]:
+    """Indices of the independent image pairs this rank owns (round-robin)."""
+    if world < 1 or not 0 <= rank < world:
+        msg = f"invalid rank {rank} for world size {world}"
+        raise ValueError(msg)
+    return list(range(rank, n_items, world))
+
+
+def gather_results(local: list[tuple[int, torch.Tensor]], n_items: int) -> list[torch.Tensor | None]:
+    """All-gather (index, image) results so every rank ends with the full, ordered list.
+
+    All images must share one shape/dtype (the benchmark's case); ranks with fewer items pad.
+    """
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world == 1:
+        out: list[torch.Tensor | None] = [None] * n_items
+        for idx, img in local:
+            out[idx] = img
+        return out
+    per_rank = (n_items + world - 1) // world
+    proto = local[0][1] if local else None
+    shapes = [None] * world
+    dist.all_gather_object(shapes, None if proto is None else (tuple(proto.shape), str(proto.dtype), str(proto.device)))
+    shape, dtype_s, _ = next(s for s in shapes if s is not None)
+    dtype = getattr(torch, dtype_s.split(".")[-1])
+    device = proto.device if proto is not None else (
+        torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu"))
+    idx_t = torch.full((per_rank,), -1, dtype=torch.int64, device=device)
+    buf = torch.zeros((per_rank, *shape), dtype=dtype, device=device)
+    for k, (idx, img) in enumerate(local):
+        idx_t[k] = idx
+        buf[k].copy_(img)
+    all_idx = [torch.empty_like(idx_t) for _ in range(world)]
+    all_buf = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(all_idx, idx_t)
+    dist.all_gather(all_buf, buf)
+    out = [None] * n_items
+    for ids, imgs in zip(all_idx, all_buf, strict=True):
+        for k, idx in enumerate(ids.tolist()):
+            if idx >= 0:
+                out[idx] = imgs[k]
+    return out

@@ -1,0 +1,49 @@
+"""The C-ABI library loads on a machine without a GPU and exports every symbol include/stv.h declares."""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+
+from style_transfer_visualizer_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols() -> set[str]:
+    text = open(os.path.join(ROOT, "include", "stv.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return set(re.findall(r"\b(stv_[a-z0-9_]+)\s*\(", text))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = _lib.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 25
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/stv.h but not exported"
+    assert declared == set(_lib.SIGNATURES), "ctypes SIGNATURES out of sync with include/stv.h"
+
+
+def test_version_and_sizing_helpers_run_without_gpu():
+    lib = _lib.load()
+    assert lib.stv_version() >= 100
+    # pure host arithmetic, no device work
+    assert lib.stv_gram_ksplit(1 << 20, 64) >= 1
+    assert lib.stv_gram_partials_bytes(4096, 512) == lib.stv_gram_ksplit(4096, 512) * 512 * 512 * 4
+    assert lib.stv_lbfgs_workspace_bytes(3 * 64 * 64, 100) > 2 * 101 * 3 * 64 * 64 * 4
+    assert lib.stv_lbfgsc_workspace_bytes(3 * 64 * 64, 100) > 2 * 101 * 3 * 64 * 64 * 4
+    assert lib.stv_gram_loss_parts(64) * 32 >= 64 * 64
+
+
+def test_op_struct_layout_matches_header():
+    # stv_op_t: 8 int32, 1 int64, 4 float, 8 pointers
+    assert ctypes.sizeof(_lib.StvOp) == 8 * 4 + 8 + 4 * 4 + 8 * 8
+
+
+def test_bad_arguments_are_rejected_not_executed():
+    lib = _lib.load()
+    # null pointers -> STV_ERR_ARG before any HIP call
+    assert lib.stv_conv_igemm(None, None, None, None, None, 8, 8, 16, 16, 9, 0, 0, None) == 1
+    assert lib.stv_gram_partial(None, None, 10, 64, 0, None) == 1
+    assert lib.stv_lbfgs_step(None, None, None, None, 10, 100, 0, 1.0, 1e-7, 1e-9, None) == 1

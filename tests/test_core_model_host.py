@@ -1,0 +1,135 @@
+"""core_model host logic that runs without a GPU: init modes, block slicing, schedule lowering,
+and the loud failure of the HIP path on CPU tensors."""
+from __future__ import annotations
+
+import pytest
+import torch
+from torch import nn
+
+from style_transfer_visualizer_amd import _lib, core_model, plan, synthetic
+
+CPU = torch.device("cpu")
+
+
+@pytest.fixture
+def vgg19(monkeypatch):
+    monkeypatch.setattr(core_model, "initialize_vgg", lambda: core_model.build_vgg_features().eval())
+
+
+def test_initialize_input_modes_and_errors():
+    content = torch.rand(1, 3, 8, 8)
+    same = core_model.initialize_input(content, "content")
+    assert torch.equal(same, content) and same.requires_grad and not content.requires_grad
+    assert torch.equal(core_model.initialize_input(content, "white"), torch.ones_like(content))
+    rnd = core_model.initialize_input(content, "random")
+    assert rnd.shape == content.shape and not torch.allclose(rnd, content)
+    with pytest.raises(ValueError, match="Unsupported initialization method: blue"):
+        core_model.initialize_input(content, "blue")
+    with pytest.raises(TypeError, match=r"Expected content_img to be a Tensor"):
+        core_model.initialize_input("nope", "content")
+
+
+def test_vgg19_topology_and_default_slicing(vgg19):
+    model = core_model.StyleContentModel([0, 5, 10, 19, 28], [21])
+    assert len(model.vgg_blocks) == 6
+    assert model.style_ids == [0, 1, 2, 3, 5] and model.content_ids == [4]
+    layers = [l for b in model.vgg_blocks for l in b]
+    assert len(layers) == 29                                # layers 29..36 are dropped
+    assert sum(isinstance(l, nn.Conv2d) for l in layers) == 13
+    assert sum(isinstance(l, nn.MaxPool2d) for l in layers) == 4
+    assert all(not l.inplace for l in layers if isinstance(l, nn.ReLU))
+    assert model.style_targets is None and model.content_targets is None
+
+
+def test_synthetic_weights_are_deterministic_and_he_scaled():
+    a = synthetic.synthetic_conv_weights(0)
+    b = synthetic.synthetic_conv_weights(0)
+    assert len(a) == 16 and all(torch.equal(x[0], y[0]) for x, y in zip(a, b))
+    w = a[5][0]
+    assert w.shape == (256, 256, 3, 3)
+    assert float(w.std()) == pytest.approx((2.0 / (9 * 256)) ** 0.5, rel=0.02)
+    assert not torch.equal(a[0][0], synthetic.synthetic_conv_weights(1)[0][0])
+    img = synthetic.synthetic_image(0, 4, 5, normalize=False)
+    assert img.shape == (1, 3, 4, 5) and 0 <= float(img.min()) and float(img.max()) < 1
+
+
+def test_no_cpu_fallback(vgg19):
+    model = core_model.StyleContentModel([0, 5], [2])
+    x = torch.rand(1, 3, 16, 16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model.set_targets(x, x)
+    model.style_targets, model.content_targets = [x], [x]
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model(x)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model.loss_and_grad(x, 1.0, 1.0)
+    model.style_targets = None
+    with pytest.raises(RuntimeError, match="style_targets must be set before computing losses."):
+        model(x)
+    model.style_targets, model.content_targets = [x], None
+    with pytest.raises(RuntimeError, match="content_targets must be set before computing losses."):
+        model(x)
+
+
+def test_precision_selection(monkeypatch):
+    assert core_model.resolve_precision(None) == torch.float32
+    assert core_model.resolve_precision("bf16") == torch.bfloat16
+    monkeypatch.setenv("STV_PRECISION", "bf16")
+    assert core_model.resolve_precision(None) == torch.bfloat16
+    with pytest.raises(ValueError, match="Unsupported precision"):
+        core_model.resolve_precision("fp8")
+
+
+def _layers():
+    return list(core_model.build_vgg_features().eval().children())
+
+
+def test_schedule_lowering_for_default_vgg19():
+    """Buffers and op flags of the lowered forward/backward schedule (no device work: CPU tensors)."""
+    s = plan.Schedule(_layers(), [0, 5, 10, 19, 28], [21], 64, 48, torch.float32, CPU, with_grad=True)
+    kinds = [n.kind for n in s.nodes]
+    assert kinds.count("conv_first") == 1 and kinds.count("conv") == 12 and kinds.count("pool") == 4
+    assert "relu" not in kinds                               # every ReLU is fused or applied on load
+    assert len(s.style_taps) == 5 and len(s.content_taps) == 1
+    tapped = [n for n in s.nodes if n.dst.taps]
+    assert [n.layer for n in tapped] == [0, 5, 10, 19, 21, 28]
+    assert all(not n.dst.relu_fused for n in tapped)         # taps are pre-ReLU conv outputs (F6)
+    assert all(n.dst.relu_fused for n in s.nodes if n.kind == "conv" and not n.dst.taps)
+    # consumers of a tapped conv apply the ReLU while staging
+    assert [n.layer for n in s.nodes if n.relu_in] == [2, 7, 12, 21, 23]
+    assert (s.nodes[-1].dst.H, s.nodes[-1].dst.W, s.nodes[-1].dst.C) == (4, 3, 512)
+
+    x = torch.zeros(1, 3, 64, 48)
+    fwd = s.forward_ops(x)
+    assert [o.op for o in fwd].count(_lib.OP_CONV) == 12 and fwd[0].op == _lib.OP_CONV_FIRST_FWD
+    for tap in s.style_taps:
+        tap.sgrad = torch.zeros(1, tap.buf.C, tap.buf.C)
+    for tap in s.content_taps:
+        tap.target = torch.zeros_like(tap.buf.act)
+    bwd = s.backward_ops(torch.zeros_like(x), style_coef=1.0, content_coef=1.0, coef_dev=None)
+    ops_ = [o.op for o in bwd]
+    assert ops_.count(_lib.OP_CONV) == 12 + 5               # 12 dgrads + 5 Gram products (1x1)
+    assert ops_.count(_lib.OP_POOL_BWD) == 4 and ops_.count(_lib.OP_CONTENT_GRAD) == 1
+    assert ops_[-1] == _lib.OP_CONV_FIRST_DGRAD and ops_[0] == _lib.OP_CONV and bwd[0].taps == 1
+    dgrads = [o for o in bwd if o.op == _lib.OP_CONV and o.taps == 9]
+    # a dgrad masks when its target is a conv output behind a ReLU; the 4 dgrads that write a pooled
+    # gradient do not - there the mask is applied by the max-pool backward on the pre-pool buffer
+    assert sum(bool(o.flags & _lib.MASK) for o in dgrads) == 8
+    assert all(o.flags & _lib.MASK for o in bwd if o.op == _lib.OP_POOL_BWD)
+    # a gradient buffer is stored once, then accumulated into
+    first_writer = {}
+    for o in bwd:
+        if o.op in (_lib.OP_CONV, _lib.OP_POOL_BWD, _lib.OP_CONTENT_GRAD):
+            acc = bool(o.flags & _lib.ACCUM)
+            assert acc == (o.q0 in first_writer), "first write must store, later ones accumulate"
+            first_writer[o.q0] = True
+
+
+def test_schedule_handles_taps_on_relu_and_pool_outputs():
+    layers = list(core_model.build_vgg_features(None, (4, 4, "M")).children())   # conv relu conv relu pool
+    s = plan.Schedule(layers, [0, 2, 4], [1, 3], 16, 16, torch.float32, CPU, with_grad=True)
+    assert [n.kind for n in s.nodes] == ["conv_first", "relu", "conv", "relu", "pool"]
+    assert [t.buf is s.nodes[i].dst for t, i in zip(s.style_taps, (0, 2, 4))] == [True] * 3
+    assert [t.buf is s.nodes[i].dst for t, i in zip(s.content_taps, (1, 3))] == [True] * 2
+    with pytest.raises(RuntimeError, match="has no HIP kernel"):
+        plan.Schedule([nn.Conv2d(3, 4, 5, padding=2)], [0], [], 8, 8, torch.float32, CPU, with_grad=False)
