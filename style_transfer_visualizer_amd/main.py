@@ -1,0 +1,57 @@
+"""Top-level orchestration: the production caller of the hot path (reference main.py:20-167).
+
+validate -> seed -> device -> load images -> model/targets/optimizer -> run -> save PNG ->
+``input_img.detach().clamp(0, 1)``.  Timelapse video / GIF encoding is presentation and is not
+part of this build: any ``FrameSink`` may be injected, otherwise video requests are downgraded
+with a warning and the run proceeds like ``--no-video``.
+"""
+from __future__ import annotations
+
+from pathlib import Path
+
+import torch
+
+from . import core_model, image_io, optimization, runtime
+from .logging_utils import logger
+from .type_defs import InputPaths, SaveOptions
+
+
+def style_transfer(paths: InputPaths, config, *, video_writer=None, gif_collector=None) -> torch.Tensor:
+    """Run one style transfer; returns the optimised image clamped to [0, 1]."""
+    runtime.validate_input_paths(paths.content_path, paths.style_path)
+    runtime.validate_parameters(config.video.quality)
+
+    if config.video.final_only:                 # reference main.py:30-33
+        config.video.create_video = False
+        config.video.create_gif = False
+        config.video.save_every = config.optimization.steps + 1
+    if (config.video.create_video and video_writer is None) or (config.video.create_gif and gif_collector is None):
+        logger.warning("Timelapse encoding is not part of the MI355X build; continuing without video/GIF "
+                       "(pass --no-video to silence this, or inject a frame sink).")
+        config.video.create_video = video_writer is not None
+        config.video.create_gif = gif_collector is not None
+
+    runtime.setup_random_seed(config.optimization.seed)
+    device = runtime.setup_device(config.hardware.device)
+    normalize = config.optimization.normalize
+    content_img = image_io.load_image_to_tensor(paths.content_path, device, normalize=normalize)
+    style_img = image_io.load_image_to_tensor(paths.style_path, device, normalize=normalize)
+
+    model, input_img, optimizer = core_model.prepare_model_and_input(
+        content_img, style_img, device, config.optimization, precision=config.hardware.precision)
+
+    output_path = runtime.setup_output_directory(config.output.output)
+    content_name, style_name = Path(paths.content_path).stem, Path(paths.style_path).stem
+
+    runner = optimization.OptimizationRunner(model, input_img, config, optimizer=optimizer,
+                                             video_writer=video_writer, gif_collector=gif_collector)
+    input_img, loss_metrics, elapsed = runner.run()
+    for sink in (video_writer, gif_collector):
+        if sink is not None:
+            sink.close()
+
+    runtime.save_outputs(input_img, loss_metrics, output_path, elapsed, SaveOptions(
+        content_name=content_name, style_name=style_name, normalize=normalize,
+        video_created=video_writer is not None, gif_created=gif_collector is not None,
+        plot_losses=config.output.plot_losses))
+    return input_img.detach().clamp(0, 1)

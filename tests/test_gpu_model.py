@@ -266,3 +266,27 @@ def test_model_errors_match_reference_texts(monkeypatch):
         model(x)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         core_model.StyleContentModel([0], [1]).set_targets(x.cpu(), x.cpu())
+
+
+def test_cli_end_to_end_writes_png(tmp_path, monkeypatch):
+    """BASELINE.json configs[0] plumbing through the CLI on the GPU: PNG in, PNG out, frame counts."""
+    from PIL import Image
+
+    from style_transfer_visualizer_amd import cli
+    monkeypatch.setenv("STV_SYNTHETIC_WEIGHTS", "0")
+    for name, seed in (("content", 0), ("style", 1)):
+        img = synthetic.synthetic_image(seed, 256, 256, normalize=False)[0].permute(1, 2, 0).mul(255).byte().numpy()
+        Image.fromarray(img).save(tmp_path / f"{name}.png")
+    out_dir = tmp_path / "out"
+    csv_path = tmp_path / "loss.csv"
+    cli.main(["--content", str(tmp_path / "content.png"), "--style", str(tmp_path / "style.png"), "--steps", "12",
+              "--init", "random", "--device", "cuda", "--no-video", "--final-only", "--seed", "0", "--output",
+              str(out_dir), "--log-loss", str(csv_path), "--log-every", "4"])
+    png = out_dir / "stylized_content_x_style.png"
+    assert png.is_file()
+    assert Image.open(png).size == (256, 256)
+    rows = csv_path.read_text().strip().splitlines()
+    assert rows[0] == "step,style_loss,content_loss,total_loss"
+    assert [r.split(",")[0] for r in rows[1:]] == ["4", "8", "12"]
+    totals = [float(r.split(",")[3]) for r in rows[1:]]
+    assert all(np.isfinite(totals)) and totals[-1] < totals[0]
