@@ -51,12 +51,19 @@ def conv_flops(meta) -> float:
     return 2.0 * max(taps, 1) * cin * cout * H * W
 
 
-def kernel_group(meta, OP) -> str | None:
+_CFG_NAMES = {0: "8, 128, 2, 2", 1: "8, 64, 4, 1", 2: "4, 128, 1, 4", 3: "4, 64, 2, 2"}
+
+
+def kernel_group(meta, OP, dtype_code: int = 1) -> str | None:
+    """Kernel (template instantiation) an op runs as - the names rocprofv3 --kernel-trace reports."""
+    from style_transfer_visualizer_amd import _lib
     op, H, W, cin, cout, taps, _n = meta
     if op == OP["CONV"]:
-        th = 4 if H <= 4 else 8
-        bn = 64 if cout <= 64 else 128
-        return f"conv_igemm<T,TH={th},BN={bn},taps={taps}>"
+        cfg = _lib.load().stv_conv_config(H, W, cin, cout, dtype_code)
+        elem = "unsigned short" if dtype_code == 1 else "float"
+        if cfg < 0:
+            return f"conv_direct_kernel<{elem}, {taps}>"
+        return f"conv_igemm_kernel<Cfg<{elem}, {_CFG_NAMES[cfg]}, {taps}>>"
     names = {OP["CONV_FIRST_FWD"]: "conv_first_fwd", OP["CONV_FIRST_DGRAD"]: "conv_first_dgrad",
              OP["POOL_FWD"]: "maxpool_fwd", OP["POOL_BWD"]: "maxpool_bwd", OP["GRAM_PARTIAL"]: "gram_partial",
              OP["GRAM_FINISH"]: "gram_finish", OP["CONTENT_LOSS"]: "content_loss",
@@ -151,7 +158,7 @@ def run_gpu(args, rank: int, world: int, device: torch.device, size: int, steps:
         ms = [sum(p[i] for p in passes) / len(passes) for i in range(prog.n_ops)]
         groups: dict = {}
         for meta, t in zip(prog.op_meta, ms, strict=True):
-            g = kernel_group(meta, OP)
+            g = kernel_group(meta, OP, 1 if args.precision == "bf16" else 0)
             e = groups.setdefault(g, {"ms": 0.0, "flops": 0.0, "launches": 0})
             e["ms"] += t
             e["launches"] += 1

@@ -77,6 +77,10 @@ int stv_conv_igemm(const void* x, const void* w, const float* bias, const void* 
                    void* y, int H, int W, int cin, int cout, int taps, int flags,
                    int dtype, void* stream);
 
+/* Which tile the dispatcher picks for a shape: -1 = scalar fallback (channel counts not a
+ * multiple of the MFMA K-slice), else 0..3 = {8x128, 8x64, 4x128, 4x64} (rows x couts). */
+int stv_conv_config(int H, int W, int cin, int cout, int dtype);
+
 /* MaxPool2d(2,2) forward / backward (first-max-wins like torch); backward
  * optionally applies the ReLU mask of the stored pre-pool activation. */
 int stv_maxpool_fwd(const void* x, void* y, int H, int W, int C, int dtype, void* stream);

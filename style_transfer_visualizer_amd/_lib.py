@@ -47,6 +47,7 @@ SIGNATURES = {
     "stv_conv_first_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "stv_conv_first_dgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "stv_conv_igemm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "stv_conv_config": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "stv_maxpool_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "stv_maxpool_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "stv_relu_fwd": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),

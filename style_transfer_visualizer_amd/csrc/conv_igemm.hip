@@ -367,11 +367,33 @@ int launch_cfg(const ConvArgs& a, hipStream_t st) {
   return STV_OK;
 }
 
+// Tile choice: -1 = direct fallback, else index into {8x128, 8x64, 4x128, 4x64} (TH x BN).
+int choose_cfg(int H, int W, int cin, int cout, int elem_bytes) {
+  const int kVec = 16 / elem_bytes, CK = 32 / elem_bytes;
+  if ((cin % CK) || (cout % kVec)) return -1;
+  // Pick the tile that finishes first: waves of workgroups over 256 CUs x work per workgroup
+  // / relative efficiency of the tile (measured with tools/conv_sweep.py).
+  static const int th[4] = {8, 8, 4, 4}, bn[4] = {128, 64, 128, 64};
+  static const float eff[4] = {1.0f, 0.92f, 0.76f, 0.70f};
+  int best = 0;
+  float best_cost = 3.4e38f;
+  for (int i = 0; i < 4; ++i) {
+    if (cout <= 64 && bn[i] == 128) continue;
+    const long blocks = (long)ceil_div(W, 32) * ceil_div(H, th[i]) * ceil_div(cout, bn[i]);
+    const float waves = (float)((blocks + 255) / 256);   // eff is per CU, whatever the residency
+    const float cost = waves * (float)(th[i] * bn[i]) / eff[i];
+    if (cost < best_cost) { best_cost = cost; best = i; }
+  }
+  if (const char* force = getenv("STV_CONV_CFG")) {   // tuning aid (tools/conv_sweep.py)
+    const int f = atoi(force);
+    if (f >= 0 && f < 4 && !(cout <= 64 && bn[f] == 128)) best = f;
+  }
+  return best;
+}
+
 template <typename T, int TAPS>
 int launch_typed(const ConvArgs& a, hipStream_t st) {
-  constexpr int kVec = elem_traits<T>::kVec;
-  constexpr int CK = 32 / (int)sizeof(T);
-  const bool mfma_ok = (a.cin % CK == 0) && (a.cout % kVec == 0);
+  const bool mfma_ok = choose_cfg(a.H, a.W, a.cin, a.cout, (int)sizeof(T)) >= 0;
   if (!mfma_ok) {
     const size_t total = (size_t)a.H * a.W * a.cout;
     hipLaunchKernelGGL((conv_direct_kernel<T, TAPS>), dim3((unsigned)((total + 255) / 256)),
@@ -379,23 +401,7 @@ int launch_typed(const ConvArgs& a, hipStream_t st) {
     STV_CHECK_LAUNCH();
     return STV_OK;
   }
-  // Pick the tile that finishes first: waves of workgroups over 256 CUs x work per workgroup
-  // / relative efficiency of the tile (bigger tiles re-read fewer weights per FLOP).
-  struct Cand { int th, bn; float eff; };
-  const Cand cands[4] = {{8, 128, 1.0f}, {8, 64, 0.92f}, {4, 128, 0.76f}, {4, 64, 0.64f}};
-  int best = 0;
-  float best_cost = 3.4e38f;
-  for (int i = 0; i < 4; ++i) {
-    if (a.cout <= 64 && cands[i].bn == 128) continue;
-    const long blocks = (long)ceil_div(a.W, 32) * ceil_div(a.H, cands[i].th) * ceil_div(a.cout, cands[i].bn);
-    const float waves = (float)((blocks + 255) / 256);   // eff is per CU, whatever the residency
-    const float cost = waves * (float)(cands[i].th * cands[i].bn) / cands[i].eff;
-    if (cost < best_cost) { best_cost = cost; best = i; }
-  }
-  if (const char* force = getenv("STV_CONV_CFG")) {   // tuning aid (tools/conv_sweep.py)
-    const int f = atoi(force);
-    if (f >= 0 && f < 4 && !(a.cout <= 64 && cands[f].bn == 128)) best = f;
-  }
+  const int best = choose_cfg(a.H, a.W, a.cin, a.cout, (int)sizeof(T));
   switch (best) {
     case 0: return launch_cfg<Cfg<T, 8, 128, 2, 2, TAPS>>(a, st);
     case 1: return launch_cfg<Cfg<T, 8, 64, 4, 1, TAPS>>(a, st);
@@ -405,6 +411,10 @@ int launch_typed(const ConvArgs& a, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" int stv_conv_config(int H, int W, int cin, int cout, int dtype) {
+  return choose_cfg(H, W, cin, cout, dtype == STV_BF16 ? 2 : 4);
+}
 
 extern "C" int stv_conv_igemm(const void* x, const void* w, const float* bias, const void* ref,
                               void* y, int H, int W, int cin, int cout, int taps, int flags,

@@ -182,7 +182,8 @@ __global__ __launch_bounds__(256) void solve_kernel(CState* st, CWs w, int hist,
   float* sSY = reinterpret_cast<float*>(smem_raw);       // [m][m] logical order
   float* sYY = sSY + (size_t)hist * hist;
   __shared__ int sh_skip, sh_pushed, sh_m, sh_head, sh_cslot, sh_mold;
-  __shared__ double sh_gs[MAX_S], sh_gy[MAX_S];
+  __shared__ float sh_newro, sh_H;
+  __shared__ double sh_gs[MAX_S], sh_gy[MAX_S], sh_ro[MAX_S];
   const int tid = threadIdx.x;
   const double* D = w.dots;
   const double* SC = w.dots + 5 * MAX_HIST;
@@ -213,6 +214,7 @@ __global__ __launch_bounds__(256) void solve_kernel(CState* st, CWs w, int hist,
           else st->hist_len += 1;
           st->ro[cslot] = 1.0f / (float)ys;
           st->H_diag = (float)ys / (float)yy;
+          sh_newro = 1.0f / (float)ys;
         }
       }
       if (st->n_iter == 1) {
@@ -225,6 +227,7 @@ __global__ __launch_bounds__(256) void solve_kernel(CState* st, CWs w, int hist,
     }
     sh_skip = skip; sh_pushed = pushed; sh_m = st->hist_len; sh_head = st->head; sh_cslot = cslot;
     sh_mold = (st->n_iter == 1) ? 0 : m_old;
+    sh_H = st->H_diag;
   }
   __syncthreads();
   if (sh_skip) return;
@@ -249,6 +252,7 @@ __global__ __launch_bounds__(256) void solve_kernel(CState* st, CWs w, int hist,
   // g-dots in (new) logical order; the pushed pair is the newest logical index m-1
   for (int i = tid; i < m; i += 256) {
     const int slot = (head + i) % S;
+    sh_ro[i] = (sh_pushed && slot == cslot) ? (double)sh_newro : (double)st->ro[slot];
     if (sh_pushed && slot == cslot) {
       sh_gs[i] = gsc;
       sh_gy[i] = gyc;
@@ -279,12 +283,12 @@ __global__ __launch_bounds__(256) void solve_kernel(CState* st, CWs w, int hist,
     if (j0 > i && j0 < m) part += cy0 * (double)sSY[i * hist + j0];
     if (j1 > i && j1 < m) part += cy1 * (double)sSY[i * hist + j1];
     part = wave_sum_d(part);
-    const double rho = (double)st->ro[(head + i) % S];
+    const double rho = sh_ro[i];
     const double al = (double)(float)((float)(cg * sh_gs[i] + part) * (float)rho);   // fp32 like torch's al[i]
     if (i == j0) { al0 = al; cy0 = -al; }
     if (i == j1) { al1 = al; cy1 = -al; }
   }
-  const double H = (double)st->H_diag;
+  const double H = (double)sh_H;
   cg *= H; cy0 *= H; cy1 *= H;
   for (int i = 0; i < m; ++i) {
     double part = 0.0;
@@ -293,7 +297,7 @@ __global__ __launch_bounds__(256) void solve_kernel(CState* st, CWs w, int hist,
     if (j0 < i) part += cs0 * (double)sSY[j0 * hist + i];
     if (j1 < i) part += cs1 * (double)sSY[j1 * hist + i];
     part = wave_sum_d(part);
-    const double rho = (double)st->ro[(head + i) % S];
+    const double rho = sh_ro[i];
     const double be = (double)(float)((float)(cg * sh_gy[i] + part) * (float)rho);
     if (i == j0) cs0 = (double)(float)((float)al0 - (float)be);
     if (i == j1) cs1 = (double)(float)((float)al1 - (float)be);
