@@ -34,6 +34,7 @@ template <typename T, int TH_, int BN_, int WM_, int WN_, int TAPS_>
 struct Cfg {
   using Elem = T;
   static constexpr int TH = TH_, BN = BN_, WM = WM_, WN = WN_, TAPS = TAPS_;
+  static constexpr int NWAVES = WM_ * WN_;           // 4 (one wave per SIMD) or 8 (two per SIMD)
   static constexpr int TW = 32;
   static constexpr int KB = 32;                      // K bytes per pixel per stage
   static constexpr int CK = KB / (int)sizeof(T);     // channels per stage
@@ -45,11 +46,11 @@ struct Cfg {
   static constexpr int W_ROWS = TAPS * BN;
   static constexpr int W_BYTES = W_ROWS * ROWB;
   static constexpr int STAGE_BYTES = IN_BYTES + W_BYTES;
-  static constexpr int PARK_ROWS = (IN_PIX + W_ROWS < 256) ? IN_PIX + W_ROWS : 256;  // idle staging lanes
-                                                                                       // write into row padding
   static constexpr int MT = TH / WM;
   static constexpr int NT = BN / WN / 32;
-  static constexpr int THREADS = 256;
+  static constexpr int THREADS = 64 * NWAVES;
+  // idle staging lanes park their write in row padding
+  static constexpr int PARK_ROWS = (IN_PIX + W_ROWS < THREADS) ? IN_PIX + W_ROWS : THREADS;
   static constexpr int IN_VECS = IN_PIX * 2;
   static constexpr int W_VECS = W_ROWS * 2;
   static constexpr int IN_ITERS = (IN_VECS + THREADS - 1) / THREADS;
@@ -58,7 +59,7 @@ struct Cfg {
   static constexpr int CS = BN + 4;                  // C-tile pitch in floats
   static constexpr int C_BYTES = BM * CS * 4;
   static constexpr int LDS_BYTES = (2 * STAGE_BYTES > C_BYTES) ? 2 * STAGE_BYTES : C_BYTES;
-  static_assert(WM * WN == 4, "4 waves per workgroup");
+  static_assert(NWAVES == 4 || NWAVES == 8, "4 or 8 waves per workgroup");
   static_assert(TH % WM == 0 && BN % (WN * 32) == 0, "tile split");
   static_assert(STAGE_BYTES % 16 == 0, "16-byte aligned stages");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -91,7 +92,7 @@ __device__ __forceinline__ void mma<float>(const f32x4& a, const f32x4& b, f32x1
 }
 
 template <typename C>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
   using T = typename C::Elem;
   using FragT = typename Frag<T>::type;
   constexpr int kVec = elem_traits<T>::kVec;
@@ -362,7 +363,7 @@ int launch_cfg(const ConvArgs& a, hipStream_t st) {
   }
   const int tiles = ceil_div(a.W, C::TW) * ceil_div(a.H, C::TH);
   dim3 grid(tiles, ceil_div(a.cout, C::BN));
-  hipLaunchKernelGGL(conv_igemm_kernel<C>, grid, dim3(256), C::LDS_BYTES, st, a);
+  hipLaunchKernelGGL(conv_igemm_kernel<C>, grid, dim3(C::THREADS), C::LDS_BYTES, st, a);
   STV_CHECK_LAUNCH();
   return STV_OK;
 }
@@ -374,7 +375,7 @@ int choose_cfg(int H, int W, int cin, int cout, int elem_bytes) {
   // Pick the tile that finishes first: waves of workgroups over 256 CUs x work per workgroup
   // / relative efficiency of the tile (measured with tools/conv_sweep.py).
   static const int th[4] = {8, 8, 4, 4}, bn[4] = {128, 64, 128, 64};
-  static const float eff[4] = {1.0f, 0.92f, 0.76f, 0.70f};
+  static const float eff[4] = {1.0f, 0.89f, 0.68f, 0.70f};
   int best = 0;
   float best_cost = 3.4e38f;
   for (int i = 0; i < 4; ++i) {
@@ -403,8 +404,9 @@ int launch_typed(const ConvArgs& a, hipStream_t st) {
   }
   const int best = choose_cfg(a.H, a.W, a.cin, a.cout, (int)sizeof(T));
   switch (best) {
-    case 0: return launch_cfg<Cfg<T, 8, 128, 2, 2, TAPS>>(a, st);
-    case 1: return launch_cfg<Cfg<T, 8, 64, 4, 1, TAPS>>(a, st);
+    // the two 8-row tiles run 8 waves (two per SIMD: one wave's waits hide under the other's MFMAs)
+    case 0: return launch_cfg<Cfg<T, 8, 128, 4, 2, TAPS>>(a, st);   // 64 px x 64 couts per wave
+    case 1: return launch_cfg<Cfg<T, 8, 64, 4, 2, TAPS>>(a, st);    // 64 px x 32 couts per wave
     case 2: return launch_cfg<Cfg<T, 4, 128, 1, 4, TAPS>>(a, st);
     default: return launch_cfg<Cfg<T, 4, 64, 2, 2, TAPS>>(a, st);
   }
