@@ -236,6 +236,9 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the additional 1024x1024 measurement")
     ap.add_argument("--per-op", default=None, help="append a per-op device-time table to this file")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (default); gloo only to rehearse N>1 on a single GPU")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -244,12 +247,15 @@ def main() -> None:
     if not torch.cuda.is_available():
         print(json.dumps({"error": "no GPU: the HIP hot path has no CPU fallback"}))
         sys.exit(2)
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", 0 if args.share_gpu else local_rank)
     torch.cuda.set_device(device)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     info = run_gpu(args, rank, world, device, args.size, args.steps, args.warmup)
     extra = None
