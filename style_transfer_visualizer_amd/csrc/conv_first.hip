@@ -127,19 +127,25 @@ __global__ __launch_bounds__(256) void conv_first_fwd_c64(const float* __restric
   }
   __syncthreads();
   const int py = tid / FT, px = tid % FT;
-  float acc[CO];
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  f32x2 acc2[CO / 2];
 #pragma unroll
-  for (int n = 0; n < CO; ++n) acc[n] = bias ? bias[n] : 0.0f;
+  for (int n = 0; n < CO / 2; ++n) acc2[n] = bias ? f32x2{bias[2 * n], bias[2 * n + 1]} : f32x2{0.0f, 0.0f};
   // 27 (tap, channel) steps, NOT unrolled: each step streams its 64 weights through SGPRs;
-  // unrolling would hoist all 1728 scalar loads and spill the scalar file
+  // unrolling would hoist all 1728 scalar loads and spill the scalar file.  Packed FMAs
+  // (v_pk_fma_f32: two output channels per instruction) halve the VALU issue count.
 #pragma unroll 1
   for (int tc = 0; tc < 27; ++tc) {
     const int tap = tc / 3, c = tc - tap * 3;
     const float xv = xs[c][py + tap / 3][px + tap % 3];
-    const float* __restrict__ wp = wt + tc * CO;               // wave-uniform -> scalar loads
+    const f32x2 xv2 = {xv, xv};
+    const f32x2* __restrict__ wp = reinterpret_cast<const f32x2*>(wt + tc * CO);   // wave-uniform -> scalar loads
 #pragma unroll
-    for (int n = 0; n < CO; ++n) acc[n] = fmaf(xv, wp[n], acc[n]);
+    for (int n = 0; n < CO / 2; ++n) acc2[n] = __builtin_elementwise_fma(xv2, wp[n], acc2[n]);
   }
+  float acc[CO];
+#pragma unroll
+  for (int n = 0; n < CO / 2; ++n) { acc[2 * n] = acc2[n][0]; acc[2 * n + 1] = acc2[n][1]; }
   // own pixel row -> LDS, then the block stores whole contiguous rows
   char* mine = os + tid * OPITCH;
   constexpr int kVec = elem_traits<T>::kVec;
@@ -180,7 +186,8 @@ __global__ __launch_bounds__(256) void conv_first_dgrad_c64(const T* __restrict_
   }
   __syncthreads();
   const int py = tid / FT, px = tid % FT;
-  float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  f32x2 p0 = {0.0f, 0.0f}, p1 = {0.0f, 0.0f}, p2 = {0.0f, 0.0f};   // (even, odd) channel partial sums
   // dx[q] = sum_tap dy[q - off(tap)] w[tap]; with t' = 8 - tap the read offset is +off(t'), and wd is
   // packed in that (already flipped) order
 #pragma unroll 1
@@ -192,13 +199,15 @@ __global__ __launch_bounds__(256) void conv_first_dgrad_c64(const T* __restrict_
       float g[kVec];
       unpack16<T>(*reinterpret_cast<const u32x4*>(src + v * 16), g);
 #pragma unroll
-      for (int e = 0; e < kVec; ++e) {
-        a0 = fmaf(g[e], wp[0 * CO + v * kVec + e], a0);
-        a1 = fmaf(g[e], wp[1 * CO + v * kVec + e], a1);
-        a2 = fmaf(g[e], wp[2 * CO + v * kVec + e], a2);
+      for (int e = 0; e < kVec; e += 2) {      // v_pk_fma_f32: two channels per instruction
+        const f32x2 g2 = {g[e], g[e + 1]};
+        p0 = __builtin_elementwise_fma(g2, *reinterpret_cast<const f32x2*>(wp + 0 * CO + v * kVec + e), p0);
+        p1 = __builtin_elementwise_fma(g2, *reinterpret_cast<const f32x2*>(wp + 1 * CO + v * kVec + e), p1);
+        p2 = __builtin_elementwise_fma(g2, *reinterpret_cast<const f32x2*>(wp + 2 * CO + v * kVec + e), p2);
       }
     }
   }
+  const float a0 = p0[0] + p0[1], a1 = p1[0] + p1[1], a2 = p2[0] + p2[1];
   const int gy = y0 + py, gx = x0 + px;
   if (gy < H && gx < W) {
     const size_t plane = (size_t)H * W, o = (size_t)gy * W + gx;

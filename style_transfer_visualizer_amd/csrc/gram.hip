@@ -402,11 +402,16 @@ int partial_typed(const void* F, float* partials, int N, int C, hipStream_t st) 
 }  // namespace
 
 extern "C" int stv_gram_ksplit(int n_pixels, int channels) {
+  // Split the pixel axis so that (a) the grid fills the chip, (b) the fp32 partial slabs the
+  // finish kernel has to re-read stay below the size of the feature map itself.
   const int TS = gram_tile(channels);
   const int nt = ceil_div(channels, TS);
   const int pairs = nt * (nt + 1) / 2;
-  int ks = 512 / pairs;
-  const int max_ks = ceil_div(n_pixels, 128);
+  const int lo = ceil_div(128, pairs), hi = (512 / pairs) > 0 ? 512 / pairs : 1;
+  int ks = n_pixels / (2 * channels);
+  if (ks < lo) ks = lo;
+  if (ks > hi) ks = hi;
+  const int max_ks = ceil_div(n_pixels, 64);
   if (ks > max_ks) ks = max_ks;
   if (ks < 1) ks = 1;
   return ks;

@@ -274,33 +274,51 @@ __global__ __launch_bounds__(256) void solve_kernel(CState* st, CWs w, int hist,
   if (tid >= 64) return;
 
   // ---- one wave: torch's two-loop on coefficients; lane owns logical indices lane, lane+64 ----
+  // Written as broadcast + rank-1 updates: when alpha_i (beta_i) becomes known its owner lane
+  // broadcasts it with v_readlane and every other lane folds it into the running sum of the
+  // indices it owns, so the serial chain per iteration is one FMA + one readlane instead of a
+  // 6-step cross-lane reduction.
   const int lane = tid;
   const int j0 = lane, j1 = lane + 64;
+  auto bcast = [](double v, int src) -> double {          // src is wave-uniform
+    const long long bits = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(bits & 0xFFFFFFFFll), src);
+    const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), src);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+  };
+  const double gs0 = j0 < m ? sh_gs[j0] : 0.0, gs1 = j1 < m ? sh_gs[j1] : 0.0;
+  const double gy0 = j0 < m ? sh_gy[j0] : 0.0, gy1 = j1 < m ? sh_gy[j1] : 0.0;
+  const double ro0 = j0 < m ? sh_ro[j0] : 0.0, ro1 = j1 < m ? sh_ro[j1] : 0.0;
   double cy0 = 0.0, cy1 = 0.0, cs0 = 0.0, cs1 = 0.0, al0 = 0.0, al1 = 0.0;
+  double a0 = 0.0, a1 = 0.0;                // sum_{j > own} cy_j * SY[own][j], built incrementally
   double cg = -1.0;
   for (int i = m - 1; i >= 0; --i) {
-    double part = 0.0;
-    if (j0 > i && j0 < m) part += cy0 * (double)sSY[i * hist + j0];
-    if (j1 > i && j1 < m) part += cy1 * (double)sSY[i * hist + j1];
-    part = wave_sum_d(part);
-    const double rho = sh_ro[i];
-    const double al = (double)(float)((float)(cg * sh_gs[i] + part) * (float)rho);   // fp32 like torch's al[i]
+    const bool hi = i >= 64;                 // wave-uniform: which owned slot holds index i
+    const double cand = (double)(float)((float)(cg * (hi ? gs1 : gs0) + (hi ? a1 : a0)) * (float)(hi ? ro1 : ro0));
+    const double al = bcast(cand, i & 63);   // fp32-rounded like torch's al[i]
     if (i == j0) { al0 = al; cy0 = -al; }
     if (i == j1) { al1 = al; cy1 = -al; }
+    if (j0 < i) a0 -= al * (double)sSY[j0 * hist + i];
+    if (j1 < i) a1 -= al * (double)sSY[j1 * hist + i];
   }
   const double H = (double)sh_H;
   cg *= H; cy0 *= H; cy1 *= H;
+  // b_own = cg*(g.y_own) + sum_j cy_j * YY[own][j]  (no recursion: cy is final)
+  double b0 = cg * gy0, b1 = cg * gy1;
+  for (int j = 0; j < m; ++j) {
+    const double cyj = bcast(j >= 64 ? cy1 : cy0, j & 63);
+    if (j0 < m) b0 += cyj * (double)sYY[j0 * hist + j];
+    if (j1 < m) b1 += cyj * (double)sYY[j1 * hist + j];
+  }
   for (int i = 0; i < m; ++i) {
-    double part = 0.0;
-    if (j0 < m) part += cy0 * (double)sYY[i * hist + j0];
-    if (j1 < m) part += cy1 * (double)sYY[i * hist + j1];
-    if (j0 < i) part += cs0 * (double)sSY[j0 * hist + i];
-    if (j1 < i) part += cs1 * (double)sSY[j1 * hist + i];
-    part = wave_sum_d(part);
-    const double rho = sh_ro[i];
-    const double be = (double)(float)((float)(cg * sh_gy[i] + part) * (float)rho);
-    if (i == j0) cs0 = (double)(float)((float)al0 - (float)be);
-    if (i == j1) cs1 = (double)(float)((float)al1 - (float)be);
+    const bool hi = i >= 64;
+    const double be = (double)(float)((float)(hi ? b1 : b0) * (float)(hi ? ro1 : ro0));
+    const double cand = (double)(float)((float)(hi ? al1 : al0) - (float)be);
+    const double csi = bcast(cand, i & 63);
+    if (i == j0) cs0 = csi;
+    if (i == j1) cs1 = csi;
+    if (j0 > i && j0 < m) b0 += csi * (double)sSY[i * hist + j0];   // (y_own . s_i) = SY[i][own]
+    if (j1 > i && j1 < m) b1 += csi * (double)sSY[i * hist + j1];
   }
   double gtd = 0.0;
   if (j0 < m) gtd += cy0 * sh_gy[j0] + cs0 * sh_gs[j0];
