@@ -52,6 +52,18 @@ def run_layer(layer: Layer, x: torch.Tensor) -> torch.Tensor:
     raise ValueError(msg)
 
 
+class _RoundBf16(torch.autograd.Function):
+    """Round to bf16 storage in both directions (activation going forward, its gradient coming back)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().to(g.dtype)
+
+
 def gram_matrix(t: torch.Tensor, clamp_max: float = GRAM_CLAMP_MAX) -> torch.Tensor:
     """core_model.py:29-63: clamp(F F^T, max) / (b*c*h*w), batch folded in."""
     b, c, h, w = t.shape
@@ -93,8 +105,22 @@ class OracleModel:
         program: Sequence[Layer],
         style_layers: Sequence[int],
         content_layers: Sequence[int],
+        *,
+        bf16_storage: bool = False,
     ) -> None:
+        """``bf16_storage`` emulates the build's performance mode on the CPU: conv weights (except
+        the first layer's) and every stored activation / activation gradient are rounded to bf16,
+        all arithmetic stays fp32.  It is NOT the reference's arithmetic; it exists to tell bf16
+        rounding effects from kernel bugs."""
+        self.bf16_storage = bf16_storage
         self.program = list(program)
+        if bf16_storage:
+            seen_conv = False
+            for i, layer in enumerate(self.program):
+                if layer[0] == "conv":
+                    if seen_conv:
+                        self.program[i] = ("conv", layer[1].bfloat16().to(layer[1].dtype), layer[2])
+                    seen_conv = True
         self.blocks, self.content_ids, self.style_ids = split_blocks(
             len(self.program), list(style_layers), list(content_layers),
         )
@@ -106,6 +132,8 @@ class OracleModel:
         for blk in self.blocks:
             for li in blk:
                 x = run_layer(self.program[li], x)
+                if self.bf16_storage and self.program[li][0] in ("conv", "pool"):
+                    x = _RoundBf16.apply(x)
             outs.append(x)
         return outs
 
