@@ -72,6 +72,28 @@ def kernel_group(meta, OP, dtype_code: int = 1) -> str | None:
     return names.get(op)
 
 
+def pmc_traffic(kernel: str, size: int) -> tuple[int | None, str | None]:
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary of this workload
+    (profiles/r01_pmc_hbm_<size>.json: FETCH_SIZE/WRITE_SIZE in separate passes, FETCH doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  bench.py cannot run the profiler itself."""
+    import re
+    path = os.path.join(ROOT, "profiles", f"r01_pmc_hbm_{size}.json")
+    if not os.path.exists(path):
+        return None, None
+
+    def key(name: str) -> str:
+        m = re.search(r"(\w+_kernel|\w+_c64)\W.*?((?:unsigned short|float)?[\d, ]*\d)\s*>", name)
+        return re.sub(r"\s+", "", (m.group(1) + "|" + m.group(2)) if m else name)
+    try:
+        data = json.load(open(path))["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None, None
+    for name, e in data.items():
+        if key(name) == key(kernel):
+            return int(e.get("hbm_bytes_per_launch", 0)) or None, os.path.relpath(path, ROOT)
+    return None, None
+
+
 def forward_bytes(sched, dtype_bytes: int) -> float:
     """SURVEY.md §8(d) byte model for forward+Gram: every tensor read once, written once."""
     total = 0.0
@@ -175,9 +197,10 @@ def run_gpu(args, rank: int, world: int, device: torch.device, size: int, steps:
         dom_name, dom = max(groups.items(), key=lambda kv: kv[1]["ms"])
         peak = BF16_PEAK_TFLOPS if args.precision == "bf16" else FP32_PEAK_TFLOPS
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+        traffic, traffic_src = pmc_traffic(dom_name, size) if args.precision == "bf16" else (None, None)
         info["roofline"] = {
             "bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": peak,
-            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
             "launches_per_step": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 5),
             "flop_per_launch": dom["flops"] / dom["launches"],
         }
