@@ -204,10 +204,9 @@ def run_gpu(args, rank: int, world: int, device: torch.device, size: int, steps:
             "launches_per_step": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 5),
             "flop_per_launch": dom["flops"] / dom["launches"],
         }
-        n_fwd = len(eng.sched.nodes)
-        fwd_gram_ms = sum(t for meta, t in zip(prog.op_meta[:n_fwd], ms[:n_fwd], strict=True))
-        fwd_gram_ms += sum(t for meta, t in zip(prog.op_meta[n_fwd:], ms[n_fwd:], strict=True)
-                           if meta[0] in (OP["GRAM_PARTIAL"], OP["GRAM_FINISH"]))
+        # forward + Gram/content losses = every op up to the score combine (SURVEY.md §8(d) byte model)
+        i_comb = next(i for i, meta in enumerate(prog.op_meta) if meta[0] == OP["LOSS_COMBINE"])
+        fwd_gram_ms = sum(ms[:i_comb])
         dtype_bytes = 2 if args.precision == "bf16" else 4
         b_fwd = forward_bytes(eng.sched, dtype_bytes)
         total_flops = sum(e["flops"] for e in groups.values())

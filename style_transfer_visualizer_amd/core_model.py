@@ -214,23 +214,39 @@ class _Engine:
         self.use_graph = os.environ.get("STV_HIP_GRAPH", "1") != "0"
 
     # -- op list pieces -------------------------------------------------------
-    def _loss_ops(self, *, style_coef: float, coef_dev: torch.Tensor | None, with_seed: bool) -> list:
+    def _tap_loss_ops(self, tap, *, style_coef: float, coef_dev: torch.Tensor | None, with_seed: bool) -> list:
+        """Loss-side ops of one tap.  They are spliced in right after the op that produces the tapped
+        activation, while it is still L2 / Infinity-Cache resident.  (Running them on a second
+        stream beside the next convolution was measured and lost 2-5 %: the conv grids that leave
+        CUs idle are too short for the extra fork/join to pay.)"""
         s = self.sched
-        out = []
-        for tap in s.style_taps:
-            lp = self.parts[tap.parts_off:]
+        if tap.kind == "style":
             cd = coef_dev[tap.order:] if coef_dev is not None else None
-            out += s.gram_ops(tap, gram_out=None, target=tap.target, loss_part=lp,
+            ops_ = s.gram_ops(tap, gram_out=None, target=tap.target, loss_part=self.parts[tap.parts_off:],
                               sgrad=tap.sgrad if with_seed else None, coef=style_coef, coef_dev=cd)
-        for tap in s.content_taps:
-            out.append(s._op(op=plan.OP_CONTENT_LOSS, p0=tap.buf.act, p1=tap.target,
-                             q0=self.parts[tap.parts_off:], n=tap.buf.act.numel()))
-        return out
+        else:
+            ops_ = [s._op(op=plan.OP_CONTENT_LOSS, p0=tap.buf.act, p1=tap.target,
+                          q0=self.parts[tap.parts_off:], n=tap.buf.act.numel())]
+        return ops_
+
+    def _forward_with_losses(self, x: torch.Tensor, *, style_coef: float, with_seed: bool) -> list:
+        def after(node):
+            out = []
+            for tap in node.dst.taps:
+                out += self._tap_loss_ops(tap, style_coef=style_coef, coef_dev=None, with_seed=with_seed)
+            return out
+        if os.environ.get("STV_LOSS_INTERLEAVE", "1") == "1":
+            return self.sched.forward_ops(x, after_node=after)
+        tail = []
+        for node in self.sched.nodes:
+            tail += after(node)
+        return self.sched.forward_ops(x) + tail
 
     def _combine_op(self, style_w: float, content_w: float):
-        return self.sched._op(op=plan.OP_LOSS_COMBINE, p0=self.parts, p1=self.table, p2=self.scale,
-                              q0=self.losses, q1=self.scores, cin=self.n_style + self.n_content,
-                              f0=style_w, f1=content_w)
+        op = self.sched._op(op=plan.OP_LOSS_COMBINE, p0=self.parts, p1=self.table, p2=self.scale,
+                            q0=self.losses, q1=self.scores, cin=self.n_style + self.n_content,
+                            f0=style_w, f1=content_w)
+        return op
 
     def _program(self, key: tuple, builder) -> plan.Program:
         prog = self._programs.get(key)
@@ -299,7 +315,7 @@ class _Engine:
 
         def build():
             s = self.sched
-            return (s.forward_ops(x) + self._loss_ops(style_coef=style_w, coef_dev=None, with_seed=True)
+            return (self._forward_with_losses(x, style_coef=style_w, with_seed=True)
                     + [self._combine_op(style_w, content_w)]
                     + s.backward_ops(grad, style_coef=style_w, content_coef=content_w, coef_dev=None))
         self._program(key, build).run(self.use_graph)
@@ -308,8 +324,7 @@ class _Engine:
         key = ("fwd", x.data_ptr())
 
         def build():
-            return (self.sched.forward_ops(x)
-                    + self._loss_ops(style_coef=0.0, coef_dev=None, with_seed=False)
+            return (self._forward_with_losses(x, style_coef=0.0, with_seed=False)
                     + [self._combine_op(1.0, 1.0)])
         self._program(key, build).run(self.use_graph)
 

@@ -196,7 +196,9 @@ class Schedule:
             setattr(op, k, v)
         return op
 
-    def forward_ops(self, x: torch.Tensor) -> list[StvOp]:
+    def forward_ops(self, x: torch.Tensor, after_node=None) -> list[StvOp]:
+        """Forward schedule; ``after_node(node)`` may return extra ops to splice in right after a
+        node's op (loss-side work that only needs that node's output)."""
         out = []
         for nd in self.nodes:
             d = nd.dst
@@ -211,6 +213,8 @@ class Schedule:
                 out.append(self._op(op=OP_POOL_FWD, p0=nd.src.act, q0=d.act, H=nd.src.H, W=nd.src.W, cin=d.C))
             else:
                 out.append(self._op(op=OP_RELU_FWD, p0=nd.src.act, q0=d.act, n=d.act.numel()))
+            if after_node is not None:
+                out += after_node(nd)
         return out
 
     def gram_ops(self, tap: Tap, *, gram_out: torch.Tensor | None, target: torch.Tensor | None,
