@@ -1,0 +1,204 @@
+"""One large image across several GPUs: row-strip partition with recomputed halos.
+
+BASELINE configs[4] (3840x2160, Adam, 4 GPUs; not in the reference - SURVEY.md §8(e)).  Rank r
+owns the image rows [c0, c1) (multiples of 16, so every max-pool window lies in one strip) and
+runs the ordinary single-GPU schedule on the *extended* strip [c0 - HALO, c1 + HALO).  HALO = 160
+rows = 2 x the receptive-field radius of conv5_1 (78 px, rounded up to a multiple of 16):
+
+* forward losses are accumulated over core rows only and reduced across ranks:
+  the raw Gram sums R = F^T F are all-reduced BEFORE the clamp (the clamp is non-linear), the
+  content squared error as one scalar;
+* the backward seeds (dF = F.S with the global S, content difference) are applied over the whole
+  extended strip: every loss term within one receptive field of a core pixel is present and was
+  computed from correct features (they are a further receptive field away from the artificial
+  strip boundary), so the gradient of the core rows is exact; halo rows of the gradient are dropped;
+* per step the ranks exchange only: 5 raw Gram matrices (2.4 MB), one scalar, and the updated core
+  strips of the image (all-gather).  No per-layer halo exchange: 26 latency-bound exchanges per
+  closure are traded for recomputing the halo rows (efficiency = core / extended rows, 62 % at 4K
+  on 4 GPUs).
+
+Adam (BASELINE configs[4]) and plain gradient evaluation are supported; L-BFGS would additionally
+need its dot products all-reduced and is not wired up here.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from . import ops, plan
+from .optimizers import HipAdam
+
+HALO_ROWS = 160
+
+
+def strip_rows(H: int, rank: int, world: int) -> tuple[int, int, int, int]:
+    """(core_begin, core_end, ext_begin, ext_end) for `rank`; strip heights are multiples of 16."""
+    base = -(-H // world)
+    base = -(-base // 16) * 16
+    c0 = min(H, rank * base)
+    c1 = min(H, c0 + base)
+    if c1 <= c0:
+        msg = f"image of {H} rows is too small for {world} strips of at least 16 rows"
+        raise ValueError(msg)
+    return c0, c1, max(0, c0 - HALO_ROWS), min(H, c1 + HALO_ROWS)
+
+
+class SpatialShard:
+    """This rank's share of one image: buffers, the two programs around the all-reduce, Adam state."""
+
+    def __init__(self, layers: list[nn.Module], style_at: list[int], content_at: list[int],
+                 content_img: torch.Tensor, style_targets: list[torch.Tensor], *, dtype: torch.dtype,
+                 style_w: float, content_w: float) -> None:
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        dev = content_img.device
+        _, _, H, W = content_img.shape
+        self.H, self.W = H, W
+        self.c0, self.c1, self.e0, self.e1 = strip_rows(H, self.rank, self.world)
+        self.style_w, self.content_w = float(style_w), float(content_w)
+        He = self.e1 - self.e0
+        self.sched = s = plan.Schedule(layers, style_at, content_at, He, W, dtype, dev, with_grad=True)
+        self.x_ext = torch.zeros(1, 3, He, W, device=dev)
+        self.g_ext = torch.zeros(1, 3, He, W, device=dev)
+
+        # down-sampling factor of every activation (doubles at each max-pool)
+        factor: dict[int, int] = {}
+        for nd in s.nodes:
+            k_src = 1 if nd.src is None else factor[id(nd.src)]
+            factor[id(nd.dst)] = k_src * 2 if nd.kind == "pool" else k_src
+        self._factor = factor
+
+        def core_rows(buf: plan.Buf) -> tuple[int, int]:
+            k = factor[id(buf)]
+            r0 = (self.c0 - self.e0) // k
+            r1 = buf.H if self.c1 >= H else (self.c1 - self.e0) // k
+            return r0, r1
+
+        # --- content targets: features of the content image on this extended strip ---
+        plan.Program(s.forward_ops(content_img[:, :, self.e0:self.e1].contiguous()), s._keep).run()
+        for tap in s.content_taps:
+            tap.target = tap.buf.act.clone()
+        n_terms = len(s.style_taps) + len(s.content_taps)
+        self.r_local = [torch.zeros(t.buf.C, t.buf.C, device=dev) for t in s.style_taps]
+        self.flat = torch.zeros(sum(r.numel() for r in self.r_local) + len(s.content_taps), device=dev)
+        self.parts_c = torch.zeros(ops._lib.CONTENT_LOSS_PARTS * max(1, len(s.content_taps)), device=dev)
+        self.losses = torch.zeros(max(n_terms, 1), device=dev)
+        self.scores = torch.zeros(4, device=dev)
+
+        # --- program 1: forward, raw Gram sums and content squared error over CORE rows ---
+        p1 = s.forward_ops(self.x_ext)
+        self._views = []
+        for tap, r in zip(s.style_taps, self.r_local, strict=True):
+            r0, r1 = core_rows(tap.buf)
+            core = tap.buf.act[r0:r1]
+            n = (r1 - r0) * tap.buf.W
+            tap.partials = torch.empty(ops.gram_ksplit(n, tap.buf.C), tap.buf.C, tap.buf.C, device=dev)
+            p1.append(s._op(op=plan.OP_GRAM_PARTIAL, p0=core, q0=tap.partials, n=n, cin=tap.buf.C))
+            # finish in "raw" mode: no clamp, norm 1 -> the mirrored full matrix R
+            p1.append(s._op(op=plan.OP_GRAM_FINISH, p0=tap.partials, q0=r, n=n, cin=tap.buf.C, f0=float("inf"),
+                            f1=1.0, f2=0.0))
+            tap.target = style_targets[tap.order]
+            tap.sgrad = torch.zeros(1, tap.buf.C, tap.buf.C, device=dev, dtype=dtype)
+        for i, tap in enumerate(s.content_taps):
+            r0, r1 = core_rows(tap.buf)
+            f, t = tap.buf.act[r0:r1], tap.target[r0:r1]
+            p1.append(s._op(op=plan.OP_CONTENT_LOSS, p0=f, p1=t,
+                            q0=self.parts_c[i * ops._lib.CONTENT_LOSS_PARTS:], n=f.numel()))
+        self.p1 = plan.Program(p1, s._keep)
+
+        # --- program 2: clamp/loss/seed from the GLOBAL R, score combine, backward over the strip ---
+        rows, scale = [], []
+        off = 0
+        self.r_global = [torch.zeros_like(r) for r in self.r_local]
+        self.parts2 = torch.zeros(sum(ops.gram_loss_parts(t.buf.C) for t in s.style_taps)
+                                  + max(1, len(s.content_taps)), device=dev)
+        p2 = []
+        for tap, rg in zip(s.style_taps, self.r_global, strict=True):
+            k = factor[id(tap.buf)]
+            n_global = (H // k) * tap.buf.W
+            cnt = ops.gram_loss_parts(tap.buf.C)
+            # n = 1 selects a single slab (ksplit = 1): `rg` already is the complete raw Gram
+            p2.append(s._op(op=plan.OP_GRAM_FINISH, p0=rg, p1=tap.target, q1=self.parts2[off:], q2=tap.sgrad, n=1,
+                            cin=tap.buf.C, f0=plan.GRAM_CLAMP_MAX, f1=float(tap.buf.C * n_global), f2=self.style_w))
+            rows.append([off, cnt, 0])
+            scale.append(1.0 / float(tap.buf.C * tap.buf.C))
+            off += cnt
+        self._content_slot = off
+        self._content_scale = []
+        for tap in s.content_taps:
+            k = factor[id(tap.buf)]
+            n_global = (H // k) * tap.buf.W * tap.buf.C
+            rows.append([off, 1, 1])
+            scale.append(1.0 / float(n_global))
+            self._content_scale.append(float(tap.buf.act.numel()) / float(n_global))
+            off += 1
+        self.table = torch.tensor(rows, dtype=torch.int32, device=dev).reshape(-1, 3)
+        self.scale = torch.tensor(scale, dtype=torch.float32, device=dev)
+        p2.append(s._op(op=plan.OP_LOSS_COMBINE, p0=self.parts2, p1=self.table, p2=self.scale, q0=self.losses,
+                        q1=self.scores, cin=n_terms, f0=self.style_w, f1=self.content_w))
+        bwd = s.backward_ops(self.g_ext, style_coef=self.style_w, content_coef=self.content_w, coef_dev=None)
+        ci = 0
+        for o in bwd:     # content gradient is normalised by the GLOBAL element count
+            if o.op == plan.OP_CONTENT_GRAD:
+                o.f0 = self.content_w * self._content_scale[min(ci, len(self._content_scale) - 1)]
+                ci += 1
+        self.p2 = plan.Program(p2 + bwd, s._keep)
+
+        # --- this rank's shard of the image and its Adam state ---
+        self.x_core = torch.zeros(1, 3, self.c1 - self.c0, W, device=dev, requires_grad=True)
+        self.g_core = torch.zeros(1, 3, self.c1 - self.c0, W, device=dev)
+        self.adam: HipAdam | None = None
+
+    # ------------------------------------------------------------------------------------------
+    def loss_and_grad(self, x_full: torch.Tensor) -> torch.Tensor:
+        """Scores [style, content, total] for the whole image; d(total)/dx of the core rows in g_core."""
+        self.x_ext.copy_(x_full[:, :, self.e0:self.e1])
+        self.p1.run()
+        n_r = 0
+        for r in self.r_local:
+            self.flat[n_r:n_r + r.numel()].copy_(r.reshape(-1))
+            n_r += r.numel()
+        n_c = len(self.sched.content_taps)
+        if n_c:
+            self.flat[n_r:n_r + n_c].copy_(self.parts_c.reshape(n_c, -1).double().sum(1).float())
+        if self.world > 1:
+            dist.all_reduce(self.flat)                   # RCCL over xGMI: 2.4 MB + a scalar per step
+        n_r = 0
+        for rg in self.r_global:
+            rg.copy_(self.flat[n_r:n_r + rg.numel()].reshape(rg.shape))
+            n_r += rg.numel()
+        if n_c:
+            self.parts2[self._content_slot:self._content_slot + n_c].copy_(self.flat[n_r:n_r + n_c])
+        self.p2.run()
+        self.g_core.copy_(self.g_ext[:, :, self.c0 - self.e0:self.c1 - self.e0])
+        return self.scores[:3].clone()
+
+    def adam_step(self, x_full: torch.Tensor, lr: float = 1e-3) -> torch.Tensor:
+        """One Adam step on this rank's rows; returns the updated full image (all-gathered)."""
+        if self.adam is None:
+            with torch.no_grad():
+                self.x_core.copy_(x_full[:, :, self.c0:self.c1])
+            self.adam = HipAdam([self.x_core], lr=lr)
+        scores = self.loss_and_grad(x_full)
+        self.x_core.grad = self.g_core
+        self.adam.step()
+        out = x_full.clone()
+        if self.world > 1:
+            parts = [None] * self.world
+            dist.all_gather_object(parts, (self.c0, self.c1))     # strip bounds (tiny, host side)
+            pieces = [torch.zeros(1, 3, b - a, self.W, device=x_full.device) for a, b in parts]
+            shapes_equal = len({p.shape for p in pieces}) == 1
+            if shapes_equal:
+                dist.all_gather(pieces, self.x_core.detach())
+            else:                                                   # ragged last strip: per-rank broadcast
+                for r, p in enumerate(pieces):
+                    if r == self.rank:
+                        p.copy_(self.x_core.detach())
+                    dist.broadcast(p, src=r)
+            for (a, b), p in zip(parts, pieces, strict=True):
+                out[:, :, a:b] = p
+        else:
+            out[:, :, self.c0:self.c1] = self.x_core.detach()
+        self.last_scores = scores
+        return out
