@@ -219,6 +219,43 @@ def run_gpu(args, rank: int, world: int, device: torch.device, size: int, steps:
     return info
 
 
+def run_spatial(args, rank: int, world: int, device: torch.device) -> dict:
+    """BASELINE configs[4]: ONE 3840x2160 image, Adam, row strips across the N GPUs (strong scaling)."""
+    import torch.distributed as dist
+
+    from style_transfer_visualizer_amd import core_model, spatial, synthetic
+    os.environ.setdefault("STV_SYNTHETIC_WEIGHTS", "0")
+    H, W = 2160, 3840
+    S, C = [0, 5, 10, 19, 28], [21]
+    dtype = torch.bfloat16 if args.precision == "bf16" else torch.float32
+    content = synthetic.synthetic_image(0, H, W).to(device)
+    style = synthetic.synthetic_image(1, 1024, 1024).to(device)
+    model = core_model.StyleContentModel(S, C, precision=args.precision).to(device)
+    targets = model._engine_for(style).capture_style(style)
+    shard = spatial.SpatialShard(model._layers(), S, C, content, targets, dtype=dtype, style_w=1e5, content_w=1.0)
+    torch.manual_seed(0)
+    x = torch.randn(1, 3, H, W, generator=torch.Generator().manual_seed(0)).to(device)
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        return time.perf_counter()
+    for _ in range(args.warmup):
+        x = shard.adam_step(x, lr=1e-3)
+    t0 = fence()
+    for _ in range(args.steps):
+        x = shard.adam_step(x, lr=1e-3)
+    elapsed = fence() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return {"elapsed": elapsed, "rows": [shard.c0, shard.c1, shard.e0, shard.e1],
+            "scores": [float(v) for v in shard.last_scores.cpu()]}
+
+
 def cpu_baseline(size: int, threads: int) -> dict:
     """Reference algorithm on the host cores: the torch-CPU oracle (fp32), bounded sample."""
     from oracle import core_model_ref as ocm
@@ -261,6 +298,8 @@ def main() -> None:
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only to rehearse N>1 on a single GPU")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--spatial", action="store_true",
+                    help="BASELINE configs[4] instead: one 3840x2160 image, Adam, row strips over the N GPUs")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -279,6 +318,24 @@ def main() -> None:
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
+    if args.spatial:
+        info = run_spatial(args, rank, world, device)
+        if rank == 0:
+            print(json.dumps({
+                "metric": "optimization steps/sec, single 3840x2160 image", "value": round(args.steps / info["elapsed"], 3),
+                "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(1e3 * info["elapsed"] / args.steps, 3), "higher_is_better": True,
+                "scaling": "strong", "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32",
+                "data": "synthetic",
+                "config": {"workload": "single 3840x2160 image, Adam lr 1e-3, VGG19, row-strip partition with "
+                                       "recomputed 160-row halos (BASELINE.json configs[4])",
+                           "parallelism": f"spatial x{world}", "rank0_rows": info["rows"]},
+                "scores": info["scores"]}))
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     info = run_gpu(args, rank, world, device, args.size, args.steps, args.warmup)
     extra = None
     if not args.no_extra and args.size == 512 and world == 1:
