@@ -46,9 +46,9 @@ struct CWs {
 
 __host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-inline int tile_floats(size_t n) {   // elements per workgroup tile: keep >= 512 workgroups when possible
-  if (n >= (size_t)4096 * 512) return 4096;
-  if (n >= (size_t)2048 * 512) return 2048;
+inline int tile_floats(size_t n) {   // elements per workgroup tile: >= 256 workgroups, as fat as possible
+  if (n >= (size_t)4096 * 256) return 4096;   // (the per-vector wave reductions amortise over the tile)
+  if (n >= (size_t)2048 * 256) return 2048;
   return 1024;
 }
 
@@ -190,44 +190,52 @@ __global__ __launch_bounds__(256) void solve_kernel(CState* st, CWs w, int hist,
   const double gmax = SC[0], gl1 = SC[1], gg = SC[2], gsc = SC[3], gyc = SC[4], ys = SC[5], yy = SC[6];
 
   if (tid == 0) {
-    st->steps_seen += 1;
-    st->gmax = (float)gmax;
-    st->no_update = 0;
-    st->pushed = 0;
+    // the 64-byte header is read and written once as a block: a chain of dependent global
+    // read-modify-writes on its fields costs ~1 us each on an otherwise idle chip
+    struct Hdr { int n_iter, hist_len, head, skip, no_update, pushed, steps_seen, pad0;
+                 float t, H_diag, gtd, gmax, ys, yy, cg, pad1; };
+    static_assert(sizeof(Hdr) == 64, "header layout");
+    Hdr h = *reinterpret_cast<const Hdr*>(st);
+    h.steps_seen += 1;
+    h.gmax = (float)gmax;
+    h.no_update = 0;
+    h.pushed = 0;
     const int skip = ((float)gmax <= tol_grad) ? 1 : 0;   // opt_cond: leave every piece of state untouched
-    st->skip = skip;
+    h.skip = skip;
     int pushed = 0;
-    const int m_old = st->hist_len;
-    const int cslot = (st->head + m_old) % S;
+    const int m_old = h.hist_len;
+    const int cslot = (h.head + m_old) % S;
     if (!skip) {
-      st->n_iter += 1;
-      if (st->n_iter == 1) {
-        st->hist_len = 0;
-        st->head = 0;
-        st->H_diag = 1.0f;
+      h.n_iter += 1;
+      if (h.n_iter == 1) {
+        h.hist_len = 0;
+        h.head = 0;
+        h.H_diag = 1.0f;
       } else {
-        st->ys = (float)ys;
-        st->yy = (float)yy;
+        h.ys = (float)ys;
+        h.yy = (float)yy;
         if ((float)ys > 1e-10f) {
           pushed = 1;
-          if (st->hist_len == hist) st->head = (st->head + 1) % S;
-          else st->hist_len += 1;
+          if (h.hist_len == hist) h.head = (h.head + 1) % S;
+          else h.hist_len += 1;
           st->ro[cslot] = 1.0f / (float)ys;
-          st->H_diag = (float)ys / (float)yy;
+          h.H_diag = (float)ys / (float)yy;
           sh_newro = 1.0f / (float)ys;
         }
       }
-      if (st->n_iter == 1) {
+      if (h.n_iter == 1) {
         const float inv = 1.0f / (float)gl1;
-        st->t = ((inv < 1.0f) ? inv : 1.0f) * lr;
+        h.t = ((inv < 1.0f) ? inv : 1.0f) * lr;
       } else {
-        st->t = lr;
+        h.t = lr;
       }
-      st->pushed = pushed;
+      h.pushed = pushed;
     }
-    sh_skip = skip; sh_pushed = pushed; sh_m = st->hist_len; sh_head = st->head; sh_cslot = cslot;
-    sh_mold = (st->n_iter == 1) ? 0 : m_old;
-    sh_H = st->H_diag;
+    sh_skip = skip; sh_pushed = pushed; sh_m = h.hist_len; sh_head = h.head; sh_cslot = cslot;
+    sh_mold = (h.n_iter == 1) ? 0 : m_old;
+    sh_H = h.H_diag;
+    // cg / gtd / no_update are filled in by the recursion below (lane 0 = this thread)
+    *reinterpret_cast<Hdr*>(st) = h;
   }
   __syncthreads();
   if (sh_skip) return;
@@ -264,11 +272,14 @@ __global__ __launch_bounds__(256) void solve_kernel(CState* st, CWs w, int hist,
   }
   __threadfence_block();
   __syncthreads();
-  for (int e = tid; e < m * m; e += 256) {
-    const int i = e / m, j = e - i * m;
-    const size_t src = (size_t)((head + i) % S) * S + (head + j) % S;
-    sSY[i * hist + j] = w.SY[src];
-    sYY[i * hist + j] = w.YY[src];
+  for (int i = tid >> 6; i < m; i += 4) {            // one table row per wave, lanes along the row
+    const size_t row = (size_t)((head + i) % S) * S;
+    for (int j = tid & 63; j < m; j += 64) {
+      int col = head + j;
+      if (col >= S) col -= S;
+      sSY[i * hist + j] = w.SY[row + col];
+      sYY[i * hist + j] = w.YY[row + col];
+    }
   }
   __syncthreads();
   if (tid >= 64) return;
