@@ -46,7 +46,7 @@ enum {
   STV_RELU_OUT = 2,  /* apply max(0,.) before storing (conv+ReLU fusion) */
   STV_MASK = 4,      /* multiply result by (ref > 0): ReLU backward */
   STV_ACCUM = 8,     /* out += result instead of out = result */
-  STV_NO_BIAS = 16
+  STV_W_BLOCKED = 16 /* conv weights are K-blocked: [taps][cin/CK][cout][CK], CK = 32 bytes of `dtype` */
 };
 
 int stv_version(void);
@@ -71,8 +71,11 @@ int stv_conv_first_dgrad(const void* dy, const float* wf, float* dx_nchw,
 /* Implicit-GEMM 3x3 conv, pad 1, stride 1, NHWC.  `w` is [taps][cout][cin] in
  * `dtype` (K-contiguous rows); bias fp32[cout] or NULL.  taps = 9 (3x3) or 1
  * (1x1, used for the Gram backward product).  flags: RELU_IN, RELU_OUT,
- * MASK (needs `ref`, NHWC [H][W][cout]), ACCUM.  The same entry computes the
- * input gradient when given the flipped/transposed weights (dgrad). */
+ * MASK (needs `ref`, NHWC [H][W][cout]), ACCUM, W_BLOCKED.  The same entry
+ * computes the input gradient when given the flipped/transposed weights (dgrad).
+ * With W_BLOCKED `w` is [taps][cin/CK][cout][CK] (CK = 16 bf16 / 8 fp32 channels,
+ * cin % CK == 0): the 32-byte K slices a workgroup stages for its output channels
+ * are then contiguous, so every weight load is a fully used cache line. */
 int stv_conv_igemm(const void* x, const void* w, const float* bias, const void* ref,
                    void* y, int H, int W, int cin, int cout, int taps, int flags,
                    int dtype, void* stream);

@@ -28,6 +28,24 @@
 
 #include "stv_common.h"
 
+#ifdef STV_STAMPS   // diagnostic build only (tools/conv_stamps.cpp): per-workgroup phase time stamps
+__device__ unsigned long long g_stv_stamps[8 * 16384];
+#define STV_STAMP(k)                                                                              \
+  do {                                                                                            \
+    if (threadIdx.x == 0) {                                                                       \
+      unsigned long long* s_ = g_stv_stamps + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8;  \
+      s_[(k)] = __builtin_amdgcn_s_memtime();                                                     \
+      if ((k) == 0) s_[6] = __builtin_amdgcn_s_memrealtime();                                     \
+      if ((k) == 4) s_[7] = __builtin_amdgcn_s_memrealtime();                                     \
+    }                                                                                             \
+  } while (0)
+#else
+#define STV_STAMP(k) do {} while (0)
+#endif
+#ifndef STV_DIAG   // diagnostic builds knock out parts of the main loop (results are then wrong; timing only)
+#define STV_DIAG 0
+#endif
+
 namespace {
 
 template <typename T, int TH_, int BN_, int WM_, int WN_, int TAPS_>
@@ -40,21 +58,26 @@ struct Cfg {
   static constexpr int CK = KB / (int)sizeof(T);     // channels per stage
   static constexpr int ROWB = KB + 16;               // padded LDS row pitch
   static constexpr int HALO = (TAPS == 9) ? 1 : 0;
+  static constexpr int ND = (TAPS == 9) ? 3 : 1;     // taps per axis
   static constexpr int IN_H = TH + 2 * HALO, IN_W = TW + 2 * HALO;
   static constexpr int IN_PIX = IN_H * IN_W;
   static constexpr int IN_BYTES = IN_PIX * ROWB;
   static constexpr int W_ROWS = TAPS * BN;
   static constexpr int W_BYTES = W_ROWS * ROWB;
   static constexpr int STAGE_BYTES = IN_BYTES + W_BYTES;
-  static constexpr int MT = TH / WM;
+  static constexpr int MT = TH / WM;                 // image rows (32-pixel MFMA row blocks) per wave
   static constexpr int NT = BN / WN / 32;
+  static constexpr int AROWS = MT + 2 * HALO;        // halo-tile rows a wave reads per horizontal tap
   static constexpr int THREADS = 64 * NWAVES;
+  // staging slots (16-byte vectors): the halo tile padded to whole waves, then the weight rows,
+  // so that every (iteration, wave) pair reads from exactly one of the two tensors
+  static constexpr int IN_VECS = IN_PIX * 2;
+  static constexpr int IN_SLOTS = (IN_VECS + 63) / 64 * 64;
+  static constexpr int W_VECS = W_ROWS * 2;
+  static constexpr int SLOTS = IN_SLOTS + W_VECS;
+  static constexpr int ITERS = (SLOTS + THREADS - 1) / THREADS;
   // idle staging lanes park their write in row padding
   static constexpr int PARK_ROWS = (IN_PIX + W_ROWS < THREADS) ? IN_PIX + W_ROWS : THREADS;
-  static constexpr int IN_VECS = IN_PIX * 2;
-  static constexpr int W_VECS = W_ROWS * 2;
-  static constexpr int IN_ITERS = (IN_VECS + THREADS - 1) / THREADS;
-  static constexpr int W_ITERS = (W_VECS + THREADS - 1) / THREADS;
   static constexpr int BM = TH * TW;
   static constexpr int CS = BN + 4;                  // C-tile pitch in floats
   static constexpr int C_BYTES = BM * CS * 4;
@@ -100,7 +123,7 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & (C::NWAVES - 1);   // scalar: selects descriptors below
   const int wm = wave / C::WN, wn = wave % C::WN;
   const int r = lane & 31, h = lane >> 5;
 
@@ -113,67 +136,73 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
   const T* __restrict__ xin = static_cast<const T*>(a.x);
   const T* __restrict__ wgt = static_cast<const T*>(a.w);
   const bool relu_in = (a.flags & STV_RELU_IN) != 0;
+  const bool w_blocked = (a.flags & STV_W_BLOCKED) != 0;
+  const int nchunks = a.cin / C::CK;
+  STV_STAMP(0);
+  // this thread's slice of the bias (all its output vectors share one channel group): requested
+  // first, a global round trip is ~2 us on a busy chip and nothing else in the epilogue waits
+  constexpr int VPR = C::BN / kVec;  // output vectors per pixel of the tile
+  const int cv = tid % VPR;
+  const int n = n0 + cv * kVec;
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.bias), 0, a.bias != nullptr ? a.cout * 4 : 0, 0x00020000);
+  f32x4 bias_v[kVec / 4];           // channels past cout (and a null bias) read as zero
+#pragma unroll
+  for (int q = 0; q < kVec / 4; ++q) {
+    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (uint32_t)((n + q * 4) * 4), 0, 0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bias_v[q][e] = __uint_as_float(t[e]);
+  }
 
-  // ---- per-thread staging descriptors: byte offsets, OOB -> zero fill by the buffer range check ----
+  // ---- per-thread staging slots: byte offsets, OOB -> zero fill by the buffer range check ----
   constexpr uint32_t kOob = 0x80000000u;   // >= num_records for every tensor this kernel accepts
-  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<T*>(xin), 0, a.H * a.W * a.cin * (int)sizeof(T), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<T*>(wgt), 0, C::TAPS * a.cout * a.cin * (int)sizeof(T), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_null = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(xin), 0, 0, 0x00020000);
+  const int x_bytes = a.H * a.W * a.cin * (int)sizeof(T);
+  const int w_bytes = C::TAPS * a.cout * a.cin * (int)sizeof(T);
   const uint32_t relu_enable = relu_in ? 0xFFFFFFFFu : 0u;
-  uint32_t in_off[C::IN_ITERS];
-  int in_lds[C::IN_ITERS];
+  uint32_t s_off[C::ITERS];
+  int s_lds[C::ITERS];
+  auto slot_is_input = [&](int it) { return (it * C::THREADS + wave * 64) < C::IN_SLOTS; };   // wave-uniform
 #pragma unroll
-  for (int it = 0; it < C::IN_ITERS; ++it) {
+  for (int it = 0; it < C::ITERS; ++it) {
     const int v = it * C::THREADS + tid;
-    const int pix = v >> 1, half = v & 1;
-    const int py = pix / C::IN_W, px = pix - py * C::IN_W;
-    const int gy = y0 + py - C::HALO, gx = x0 + px - C::HALO;
-    const bool ok = (v < C::IN_VECS) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-    in_off[it] = ok ? (uint32_t)(((gy * a.W + gx) * a.cin + half * kVec) * (int)sizeof(T)) : kOob;
-    in_lds[it] = (v < C::IN_VECS) ? pix * C::ROWB + half * 16 : (tid % C::PARK_ROWS) * C::ROWB + C::KB;
-  }
-  uint32_t w_off[C::W_ITERS];
-  int w_lds[C::W_ITERS];
-#pragma unroll
-  for (int it = 0; it < C::W_ITERS; ++it) {
-    const int v = it * C::THREADS + tid;
-    const int row = v >> 1, half = v & 1;
-    const int tap = row / C::BN, n = row - tap * C::BN;
-    const bool ok = (v < C::W_VECS) && (n0 + n) < a.cout;
-    w_off[it] = ok ? (uint32_t)(((tap * a.cout + n0 + n) * a.cin + half * kVec) * (int)sizeof(T)) : kOob;
-    w_lds[it] = (v < C::W_VECS) ? C::IN_BYTES + row * C::ROWB + half * 16 : (tid % C::PARK_ROWS) * C::ROWB + C::KB;
-  }
-
-  // Two register sets: data of K-stage k lives in set (k & 1).  Stage c issues the loads of
-  // stage c+2 and writes the set loaded one stage earlier (stage c+1) into the other LDS
-  // buffer, so every global load has more than a full stage of MFMA work to land.
-  u32x4 in_reg[2][C::IN_ITERS];
-  u32x4 w_reg[2][C::W_ITERS];
-
-  // `live` = false turns every load into an out-of-range one (zero records): no traffic, no branch
-  auto stage_load = [&](auto par, int c0, bool live) {
-    constexpr int P = decltype(par)::value;
-    const uint32_t cb = (uint32_t)(c0 * (int)sizeof(T));
-    const __amdgpu_buffer_rsrc_t rx = live ? rs_x : rs_null;
-    const __amdgpu_buffer_rsrc_t rw = live ? rs_w : rs_null;
-#pragma unroll
-    for (int it = 0; it < C::IN_ITERS; ++it)
-      in_reg[P][it] = __builtin_amdgcn_raw_buffer_load_b128(rx, in_off[it] + cb, 0, 0);
-#pragma unroll
-    for (int it = 0; it < C::W_ITERS; ++it)
-      w_reg[P][it] = __builtin_amdgcn_raw_buffer_load_b128(rw, w_off[it] + cb, 0, 0);
-  };
-  // write staged vector number `k` (inputs first, then weights); branch-free: ReLU-on-load
-  // clears elements whose sign bit is set under a wave-uniform enable mask
-  auto stage_write_one = [&](auto par, char* buf, int k) {
-    constexpr int P = decltype(par)::value;
-    if (k < C::IN_ITERS) {
-      *reinterpret_cast<u32x4*>(buf + in_lds[k]) = relu16_masked<T>(in_reg[P][k], relu_enable);
+    const int park = (tid % C::PARK_ROWS) * C::ROWB + C::KB;
+    if (slot_is_input(it)) {
+      const int pix = v >> 1, half = v & 1;
+      const int py = pix / C::IN_W, px = pix - py * C::IN_W;
+      const int gy = y0 + py - C::HALO, gx = x0 + px - C::HALO;
+      const bool ok = (v < C::IN_VECS) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      s_off[it] = ok ? (uint32_t)(((gy * a.W + gx) * a.cin + half * kVec) * (int)sizeof(T)) : kOob;
+      s_lds[it] = (v < C::IN_VECS) ? pix * C::ROWB + half * 16 : park;
     } else {
-      *reinterpret_cast<u32x4*>(buf + w_lds[k - C::IN_ITERS]) = w_reg[P][k - C::IN_ITERS];
+      const int wv = v - C::IN_SLOTS;
+      const int row = wv >> 1, half = wv & 1;
+      const int tap = row / C::BN, n = row - tap * C::BN;
+      const bool ok = (wv < C::W_VECS) && (n0 + n) < a.cout;
+      const int elem = w_blocked ? ((tap * nchunks * a.cout + n0 + n) * C::CK + half * kVec)
+                                 : ((tap * a.cout + n0 + n) * a.cin + half * kVec);
+      s_off[it] = ok ? (uint32_t)(elem * (int)sizeof(T)) : kOob;
+      s_lds[it] = (wv < C::W_VECS) ? C::IN_BYTES + row * C::ROWB + half * 16 : park;
     }
+  }
+  // bytes from one K-stage to the next: 32 along a pixel's (or plain weight row's) channels,
+  // a whole [cout][CK] slab in the K-blocked weight layout
+  const int w_stride = w_blocked ? a.cout * C::KB : C::KB;
+
+  // One register per slot.  In K-stage c a slot's register (holding stage c+1, loaded during
+  // stage c-1) is written to the other LDS buffer and immediately re-loaded with stage c+2, one
+  // slot per tap, so every global load has a full stage of MFMA work to land and neither the
+  // loads nor the LDS writes arrive in a burst.
+  u32x4 sreg[C::ITERS];
+  // `live` = false turns the load into an out-of-range one (zero records): no traffic, no branch
+  auto slot_load = [&](int k, int stage, bool live) {
+    const bool in = slot_is_input(k);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(in ? xin : wgt), 0, live ? (in ? x_bytes : w_bytes) : 0, 0x00020000);
+    sreg[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, s_off[k] + (uint32_t)(stage * (in ? C::KB : w_stride)), 0, 0);
+  };
+  // branch-free: ReLU-on-load clears elements whose sign bit is set under a wave-uniform enable mask
+  auto slot_write = [&](char* buf, int k) {
+    *reinterpret_cast<u32x4*>(buf + s_lds[k]) = relu16_masked<T>(sreg[k], slot_is_input(k) ? relu_enable : 0u);
   };
 
   f32x16 acc[C::MT][C::NT];
@@ -188,76 +217,105 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
   const int a_lane = ((wm * C::MT) * C::IN_W + r) * C::ROWB + h * 16;
   const int b_lane = C::IN_BYTES + (wn * (C::NT * 32) + r) * C::ROWB + h * 16;
 
-  const int nchunks = a.cin / C::CK;
-  using P0 = std::integral_constant<int, 0>;
-  using P1 = std::integral_constant<int, 1>;
-  constexpr int NW = C::IN_ITERS + C::W_ITERS;
+  constexpr int NSTEP = C::ND * C::ND;
+  constexpr int PER = (C::ITERS + NSTEP - 1) / NSTEP;
+  // B fragments are fetched PFB steps ahead of their MFMAs: an LDS read takes ~190 cycles under
+  // load, a step only MT*NT*32 of MFMA issue, so a lone wave on a SIMD needs the deeper queue
+  constexpr int PFB = (C::MT * C::NT >= 4) ? 2 : 3;
 
-  // one K-stage with compile-time parity P = c & 1
-  auto run_stage = [&](auto par, int c) {
-    constexpr int P = decltype(par)::value;
-    using Other = std::integral_constant<int, P ^ 1>;
-    char* cur = smem + P * C::STAGE_BYTES;
-    char* nxt = smem + (P ^ 1) * C::STAGE_BYTES;
-    stage_load(par, (c + 2) * C::CK, (c + 2) < nchunks);   // set P is free: its data is in `cur`
-    __builtin_amdgcn_sched_barrier(0);                     // keep the prefetch above the MFMA stream
-
-    // fragments are software-pipelined one tap ahead (two register sets, static indices)
-    FragT bf[2][C::NT];
-    FragT af[2][C::MT];
-    auto load_frags = [&](int tap, int set) {
-      const int dy = (C::TAPS == 9) ? tap / 3 : 0;
-      const int dx = (C::TAPS == 9) ? tap % 3 : 0;
+  // One K-stage.  The taps are walked column by column (dx outer, dy inner): the MT+2 halo-tile
+  // rows a wave needs for one dx serve all three dy, so a stage reads 3*(MT+2) A fragments
+  // instead of 9*MT.  Fragments are fetched one step ahead of the MFMAs that use them.
+  auto run_stage = [&](char* cur, char* nxt, int c) {
+    FragT af[2][C::AROWS];
+    FragT bf[PFB + 1][C::NT];
+    auto load_a = [&](int dx, int j, int set) {
+      af[set][j] = *reinterpret_cast<const FragT*>(cur + a_lane + (j * C::IN_W + dx) * C::ROWB);
+    };
+    auto load_b = [&](int step) {
+      const int tap = (step % C::ND) * C::ND + step / C::ND;     // dy * 3 + dx
 #pragma unroll
       for (int nt = 0; nt < C::NT; ++nt)
-        bf[set][nt] = *reinterpret_cast<const FragT*>(cur + b_lane + (tap * C::BN + nt * 32) * C::ROWB);
-#pragma unroll
-      for (int mt = 0; mt < C::MT; ++mt)
-        af[set][mt] = *reinterpret_cast<const FragT*>(cur + a_lane + ((mt + dy) * C::IN_W + dx) * C::ROWB);
+        bf[step % (PFB + 1)][nt] = *reinterpret_cast<const FragT*>(cur + b_lane + (tap * C::BN + nt * 32) * C::ROWB);
     };
-    load_frags(0, 0);
+    load_b(0);
 #pragma unroll
-    for (int tap = 0; tap < C::TAPS; ++tap) {
-      const int set = tap & 1;
-      if (tap + 1 < C::TAPS) load_frags(tap + 1, set ^ 1);
-      // issue the next tap's LDS reads first, then this tap's MFMAs back to back: the reads
-      // (counted lgkmcnt) complete under the matrix work of a wave that has no SIMD partner
+    for (int j = 0; j < C::AROWS; ++j) load_a(0, j, 0);
+#pragma unroll
+    for (int q = 1; q < PFB; ++q)
+      if (q < NSTEP) load_b(q);
+#pragma unroll
+    for (int step = 0; step < NSTEP; ++step) {
+      const int dx = step / C::ND, dy = step % C::ND;
+      if (step + PFB < NSTEP) load_b(step + PFB);
+      if (dx + 1 < C::ND) {        // next column of A rows: first half at dy = 0, the rest at dy = 1
+#pragma unroll
+        for (int j = 0; j < C::AROWS; ++j)
+          if ((j < (C::AROWS + 1) / 2 ? 0 : 1) == dy) load_a(dx + 1, j, (dx + 1) & 1);
+      }
+      // the next step's LDS reads are issued first, then this step's MFMAs back to back
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < C::NT; ++nt) mma<T>(af[set][mt], bf[set][nt], acc[mt][nt]);
-      // spread stage c+1's LDS writes (set P^1, loaded during stage c-1) over the MFMA groups
-      if (C::TAPS == 9) {
-        constexpr int PER = (NW + 8) / 9;
-        __builtin_amdgcn_sched_barrier(0);
+        for (int nt = 0; nt < C::NT; ++nt) mma<T>(af[dx & 1][mt + dy], bf[step % (PFB + 1)][nt], acc[mt][nt]);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = tap * PER; k < (tap + 1) * PER; ++k)
-          if (k < NW) stage_write_one(Other{}, nxt, k);
-      }
-    }
-    if (C::TAPS != 9) {
-#pragma unroll
-      for (int k = 0; k < NW; ++k) stage_write_one(Other{}, nxt, k);
+      for (int k = step * PER; k < (step + 1) * PER; ++k)
+        if (k < C::ITERS) {
+          if (!(STV_DIAG & 2)) slot_write(nxt, k);
+          slot_load(k, c + 2, (c + 2) < nchunks && !(STV_DIAG & 1));
+        }
     }
     __syncthreads();
   };
 
-  // prologue: stage 0 -> LDS buffer 0, stage 1 in flight in set 1
-  stage_load(P0{}, 0, true);
-  stage_load(P1{}, C::CK, 1 < nchunks);
+  // prologue: stage 0 -> LDS buffer 0, stage 1 in flight
 #pragma unroll
-  for (int k = 0; k < NW; ++k) stage_write_one(P0{}, smem, k);
+  for (int k = 0; k < C::ITERS; ++k) slot_load(k, 0, true);
+#pragma unroll
+  for (int k = 0; k < C::ITERS; ++k) {
+    slot_write(smem, k);
+    slot_load(k, 1, 1 < nchunks);
+  }
   __syncthreads();
+  STV_STAMP(1);
 
+  char* const buf0 = smem;
+  char* const buf1 = smem + C::STAGE_BYTES;
   int c = 0;
   for (; c + 1 < nchunks; c += 2) {
-    run_stage(P0{}, c);
-    run_stage(P1{}, c + 1);
+    run_stage(buf0, buf1, c);
+    run_stage(buf1, buf0, c + 1);
   }
-  if (c < nchunks) run_stage(P0{}, c);
+  if (c < nchunks) run_stage(buf0, buf1, c);
+  STV_STAMP(2);
 
   // ---- epilogue: accumulators -> LDS C tile (fp32) -> 16-byte vector stores ----
+  // A thread's vectors all sit in the same channel group (THREADS % VPR == 0): its bias slice and
+  // every mask / accumulate operand are requested up front, before the C tile is even written.
+  constexpr int EIT = C::BM * VPR / C::THREADS;
+  static_assert(C::BM * VPR % C::THREADS == 0 && C::THREADS % VPR == 0, "epilogue split");
+  const bool relu_out = (a.flags & STV_RELU_OUT) != 0;
+  const bool do_mask = (a.flags & STV_MASK) != 0;
+  const bool do_acc = (a.flags & STV_ACCUM) != 0;
+  const int out_bytes = a.H * a.W * a.cout * (int)sizeof(T);
+  const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_ref = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(a.ref), 0, do_mask ? out_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_old = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, do_acc ? out_bytes : 0, 0x00020000);
+  uint32_t o_off[EIT];
+  u32x4 refv[EIT], oldv[EIT];
+#pragma unroll
+  for (int it = 0; it < EIT; ++it) {
+    const int pix = (it * C::THREADS + tid) / VPR;
+    const int gy = y0 + (pix >> 5), gx = x0 + (pix & 31);
+    const bool ok = gy < a.H && gx < a.W && n < a.cout;
+    o_off[it] = ok ? (uint32_t)(((gy * a.W + gx) * a.cout + n) * (int)sizeof(T)) : kOob;
+    refv[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_ref, o_off[it], 0, 0);
+    oldv[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_old, o_off[it], 0, 0);
+  }
+
   float* cs = reinterpret_cast<float*>(smem);
 #pragma unroll
   for (int mt = 0; mt < C::MT; ++mt)
@@ -270,50 +328,37 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
         cs[row * C::CS + col] = acc[mt][nt][i];
       }
   __syncthreads();
+  STV_STAMP(3);
 
-  T* __restrict__ yout = static_cast<T*>(a.y);
-  const T* __restrict__ ref = static_cast<const T*>(a.ref);
-  const bool relu_out = (a.flags & STV_RELU_OUT) != 0;
-  const bool do_mask = (a.flags & STV_MASK) != 0;
-  const bool do_acc = (a.flags & STV_ACCUM) != 0;
-  const bool has_bias = a.bias != nullptr;
-  constexpr int VPR = C::BN / kVec;  // vectors per pixel row of the tile
-  constexpr int TOTAL = C::BM * VPR;
-  for (int v = tid; v < TOTAL; v += C::THREADS) {
-    const int pix = v / VPR, cv = v - pix * VPR;
-    const int gy = y0 + (pix >> 5), gx = x0 + (pix & 31);
-    const int n = n0 + cv * kVec;
-    if (gy >= a.H || gx >= a.W || n >= a.cout) continue;
+#pragma unroll
+  for (int it = 0; it < EIT; ++it) {
+    const int pix = (it * C::THREADS + tid) / VPR;
     float val[kVec];
 #pragma unroll
     for (int q = 0; q < kVec / 4; ++q) {
       const f32x4 t = *reinterpret_cast<const f32x4*>(cs + pix * C::CS + cv * kVec + q * 4);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) val[q * 4 + e] = t[e];
-    }
-    if (has_bias) {
-#pragma unroll
-      for (int e = 0; e < kVec; ++e) val[e] += a.bias[n + e];
+      for (int e = 0; e < 4; ++e) val[q * 4 + e] = t[e] + bias_v[q][e];
     }
     if (relu_out) {
 #pragma unroll
       for (int e = 0; e < kVec; ++e) val[e] = fmaxf(val[e], 0.0f);
     }
-    const size_t o = ((size_t)gy * a.W + gx) * a.cout + n;
     if (do_mask) {
       float m[kVec];
-      unpack16<T>(*reinterpret_cast<const u32x4*>(ref + o), m);
+      unpack16<T>(refv[it], m);
 #pragma unroll
       for (int e = 0; e < kVec; ++e) val[e] = (m[e] > 0.0f) ? val[e] : 0.0f;
     }
     if (do_acc) {
       float old[kVec];
-      unpack16<T>(*reinterpret_cast<const u32x4*>(yout + o), old);
+      unpack16<T>(oldv[it], old);
 #pragma unroll
       for (int e = 0; e < kVec; ++e) val[e] += old[e];
     }
-    *reinterpret_cast<u32x4*>(yout + o) = pack16<T>(val);
+    __builtin_amdgcn_raw_buffer_store_b128(pack16<T>(val), rs_y, o_off[it], 0, 0);   // OOB lanes are dropped
   }
+  STV_STAMP(4);
 }
 
 // ---- generic direct fallback (any Cin/Cout; used for odd shapes in tests) ----
@@ -388,6 +433,7 @@ int choose_cfg(int H, int W, int cin, int cout, int elem_bytes) {
   if (const char* force = getenv("STV_CONV_CFG")) {   // tuning aid (tools/conv_sweep.py)
     const int f = atoi(force);
     if (f >= 0 && f < 4 && !(cout <= 64 && bn[f] == 128)) best = f;
+    if (f == 4 && cout > 64) best = 4;   // experimental: 8x128 with waves as 2(M) x 4(N)
   }
   return best;
 }
@@ -408,6 +454,7 @@ int launch_typed(const ConvArgs& a, hipStream_t st) {
     case 0: return launch_cfg<Cfg<T, 8, 128, 4, 2, TAPS>>(a, st);   // 64 px x 64 couts per wave
     case 1: return launch_cfg<Cfg<T, 8, 64, 4, 2, TAPS>>(a, st);    // 64 px x 32 couts per wave
     case 2: return launch_cfg<Cfg<T, 4, 128, 1, 4, TAPS>>(a, st);
+    case 4: return launch_cfg<Cfg<T, 8, 128, 2, 4, TAPS>>(a, st);
     default: return launch_cfg<Cfg<T, 4, 64, 2, 2, TAPS>>(a, st);
   }
 }
@@ -424,6 +471,8 @@ extern "C" int stv_conv_igemm(const void* x, const void* w, const float* bias, c
   if (!x || !w || !y || H <= 0 || W <= 0 || cin <= 0 || cout <= 0) return STV_ERR_ARG;
   if ((flags & STV_MASK) && !ref) return STV_ERR_ARG;
   if (taps != 9 && taps != 1) return STV_ERR_ARG;
+  // the direct fallback (shapes the matrix-core tiling does not cover) reads plain weights only
+  if ((flags & STV_W_BLOCKED) && choose_cfg(H, W, cin, cout, dtype == STV_F32 ? 4 : 2) < 0) return STV_ERR_ARG;
   if ((size_t)H * W * (size_t)(cin > cout ? cin : cout) >= (size_t)1 << 31) return STV_ERR_ARG;
   ConvArgs a{x, w, bias, ref, y, H, W, cin, cout, flags};
   hipStream_t st = static_cast<hipStream_t>(stream);

@@ -12,7 +12,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib
-from ._lib import ACCUM, MASK, RELU_IN, RELU_OUT, STV_BF16, STV_F32  # noqa: F401
+from ._lib import ACCUM, MASK, RELU_IN, RELU_OUT, STV_BF16, STV_F32, W_BLOCKED  # noqa: F401
 
 
 def dtype_code(dtype: torch.dtype) -> int:
@@ -54,6 +54,25 @@ def pack_weights_bwd(w: torch.Tensor) -> torch.Tensor:
     return w.flip(2, 3).permute(2, 3, 1, 0).reshape(9, cin, cout).contiguous()
 
 
+def block_weights(w: torch.Tensor) -> torch.Tensor:
+    """[taps,Cout,Cin] (already in the compute dtype) -> K-blocked [taps,Cin/CK,Cout,CK], CK = 32 bytes.
+
+    The layout ``STV_W_BLOCKED`` names (include/stv.h): the 32-byte K slices that one workgroup
+    stages for its output channels become contiguous in memory.
+    """
+    taps, cout, cin = w.shape
+    ck = 32 // w.element_size()
+    if cin % ck:
+        msg = f"cin={cin} is not a multiple of {ck}: this layer cannot use the K-blocked layout"
+        raise RuntimeError(msg)
+    return w.reshape(taps, cout, cin // ck, ck).permute(0, 2, 1, 3).contiguous()
+
+
+def conv_uses_mfma(H: int, W: int, cin: int, cout: int, dtype: torch.dtype) -> bool:
+    """True when stv_conv_igemm runs this shape on the matrix cores (else: direct kernel, plain weights)."""
+    return int(_lib.load().stv_conv_config(H, W, cin, cout, dtype_code(dtype))) >= 0
+
+
 def to_nhwc(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     """[1,C,H,W] -> [H,W,C] (test/fixture helper; the product never converts activations)."""
     return x[0].permute(1, 2, 0).contiguous().to(dtype)
@@ -91,9 +110,14 @@ def conv_first_dgrad(dy: torch.Tensor, wf: torch.Tensor, cin: int,
 def conv_igemm(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None,
                ref: torch.Tensor | None = None, out: torch.Tensor | None = None,
                flags: int = 0) -> torch.Tensor:
-    """x [H,W,Cin], w [taps,Cout,Cin] (same dtype) -> [H,W,Cout]."""
+    """x [H,W,Cin], w [taps,Cout,Cin] or K-blocked [taps,Cin/CK,Cout,CK] (same dtype) -> [H,W,Cout]."""
     H, W, cin = x.shape
-    taps, cout, cin_w = w.shape
+    if w.dim() == 4:
+        taps, nck, cout, ck = w.shape
+        cin_w = nck * ck
+        flags |= W_BLOCKED
+    else:
+        taps, cout, cin_w = w.shape
     if cin_w != cin or w.dtype != x.dtype:
         msg = f"weight {tuple(w.shape)}/{w.dtype} does not match input {tuple(x.shape)}/{x.dtype}"
         raise RuntimeError(msg)

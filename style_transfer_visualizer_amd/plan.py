@@ -18,6 +18,8 @@ optimization.py:292-313):
 """
 from __future__ import annotations
 
+import os
+
 import ctypes
 from dataclasses import dataclass, field
 
@@ -25,7 +27,7 @@ import torch
 from torch import nn
 
 from . import _lib, ops
-from ._lib import (ACCUM, MASK, OP_CONTENT_GRAD, OP_CONTENT_LOSS, OP_CONV, OP_CONV_FIRST_DGRAD,
+from ._lib import (ACCUM, MASK, W_BLOCKED, OP_CONTENT_GRAD, OP_CONTENT_LOSS, OP_CONV, OP_CONV_FIRST_DGRAD,
                    OP_CONV_FIRST_FWD, OP_GRAM_FINISH, OP_GRAM_PARTIAL, OP_LOSS_COMBINE, OP_POOL_BWD,
                    OP_POOL_FWD, OP_RELU_BWD, OP_RELU_FWD, RELU_IN, RELU_OUT, StvOp)
 
@@ -135,10 +137,15 @@ class Schedule:
                         raise RuntimeError(msg)
                     node = Node("conv_first", None, dst, layer=i, wf=ops.pack_weights_fwd(w), bias=bias, cin=cin)
                 else:
-                    node = Node("conv", cur, dst, relu_in=pending_relu, layer=i,
-                                wf=ops.pack_weights_fwd(w).to(self.dtype),
-                                wb=ops.pack_weights_bwd(w).to(self.dtype) if self.with_grad else None,
-                                bias=bias, cin=cin)
+                    wf = ops.pack_weights_fwd(w).to(self.dtype)
+                    wb = ops.pack_weights_bwd(w).to(self.dtype) if self.with_grad else None
+                    # matrix-core shapes take K-blocked weights (W_BLOCKED is derived from w.dim() == 4)
+                    blocked = os.environ.get("STV_W_BLOCKED", "1") != "0"     # A/B knob
+                    if blocked and ops.conv_uses_mfma(H, W, cin, cout, self.dtype):
+                        wf = ops.block_weights(wf)
+                    if blocked and wb is not None and ops.conv_uses_mfma(H, W, cout, cin, self.dtype):
+                        wb = ops.block_weights(wb)
+                    node = Node("conv", cur, dst, relu_in=pending_relu, layer=i, wf=wf, wb=wb, bias=bias, cin=cin)
                 pending_relu = False
                 if i + 1 <= last and kinds[i + 1] == "relu" and i not in tapped:
                     dst.relu_fused = True      # ReLU runs in this conv's epilogue
@@ -206,7 +213,8 @@ class Schedule:
                 out.append(self._op(op=OP_CONV_FIRST_FWD, p0=x, p1=nd.wf, p2=nd.bias, q0=d.act,
                                     H=d.H, W=d.W, cin=nd.cin, cout=d.C))
             elif nd.kind == "conv":
-                flags = (RELU_IN if nd.relu_in else 0) | (RELU_OUT if d.relu_fused else 0)
+                flags = ((RELU_IN if nd.relu_in else 0) | (RELU_OUT if d.relu_fused else 0)
+                         | (W_BLOCKED if nd.wf.dim() == 4 else 0))
                 out.append(self._op(op=OP_CONV, p0=nd.src.act, p1=nd.wf, p2=nd.bias, q0=d.act, H=d.H, W=d.W,
                                     cin=nd.cin, cout=d.C, taps=9, flags=flags))
             elif nd.kind == "pool":
@@ -272,7 +280,7 @@ class Schedule:
                 continue
             mask_src = nd.relu_in or (s.relu_fused and not s.taps)
             if nd.kind == "conv":
-                flags = (MASK if mask_src else 0) | acc_flag(s)
+                flags = (MASK if mask_src else 0) | acc_flag(s) | (W_BLOCKED if nd.wb.dim() == 4 else 0)
                 out.append(self._op(op=OP_CONV, p0=d.grad, p1=nd.wb, p3=s.act if mask_src else None, q0=s.grad,
                                     H=s.H, W=s.W, cin=d.C, cout=s.C, taps=9, flags=flags))
             elif nd.kind == "pool":

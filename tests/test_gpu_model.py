@@ -140,7 +140,10 @@ def _decision_flips(model, oracle64, x64):
         acts.append(h)
     flips, worst = 0, 0.0
     for nd in eng.sched.nodes:
-        if nd.kind in ("conv", "conv_first") and nd.dst.relu_fused:
+        # a conv output meets a ReLU either in its own epilogue (relu_fused) or, when it is tapped
+        # pre-activation, in its consumer (ReLU-on-load forward, MASK on the way back)
+        relu_later = any(n.src is nd.dst and (n.relu_in or n.kind == "relu") for n in eng.sched.nodes)
+        if nd.kind in ("conv", "conv_first") and (nd.dst.relu_fused or relu_later):
             z = acts[nd.layer]                                  # fp64 pre-activation
             hip_on = ops.from_nhwc(nd.dst.act).cpu() > 0
             diff = hip_on != (z > 0)

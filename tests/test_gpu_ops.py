@@ -81,10 +81,31 @@ CONV_CASES = [
 ]
 
 
+def _maybe_blocked(wp, blocked, H, W, cin, cout, dtype):
+    """K-blocked weights (STV_W_BLOCKED) wherever the shape runs on the matrix cores."""
+    if blocked and ops.conv_uses_mfma(H, W, cin, cout, dtype):
+        return ops.block_weights(wp)
+    if blocked:
+        pytest.skip("direct-kernel shape: plain weights only")
+    return wp
+
+
+def test_blocked_weights_rejected_on_direct_shapes():
+    x = torch.zeros(4, 4, 12, device=DEV)
+    w = torch.zeros(9, 1, 8, 8, device=DEV)          # claims cin=8 (x has 12): host check
+    with pytest.raises(RuntimeError):
+        ops.conv_igemm(x, w)
+    x = torch.zeros(4, 4, 8, device=DEV)
+    w = torch.zeros(9, 1, 6, 8, device=DEV)          # cout=6 is not vectorisable -> direct kernel -> STV_ERR_ARG
+    with pytest.raises(RuntimeError, match="STV_ERR_ARG"):
+        ops.conv_igemm(x, w)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("blocked", [False, True])
 @pytest.mark.parametrize("flags", [0, ops.RELU_IN, ops.RELU_OUT, ops.RELU_IN | ops.RELU_OUT])
-def test_conv_igemm_forward(dtype, case, flags):
+def test_conv_igemm_forward(dtype, case, flags, blocked):
     cin, cout, H, W = case
     x = rnd((1, cin, H, W), 11)
     w = rnd((cout, cin, 3, 3), 12, -1, 1) * (2.0 / (9 * cin)) ** 0.5
@@ -94,14 +115,15 @@ def test_conv_igemm_forward(dtype, case, flags):
     ref = F.conv2d(xin, wq, b, padding=1)
     if flags & ops.RELU_OUT:
         ref = F.relu(ref)
-    y = ops.conv_igemm(ops.to_nhwc(x, dtype).to(DEV), ops.pack_weights_fwd(w).to(dtype).to(DEV),
-                       b.to(DEV), flags=flags)
+    wp = _maybe_blocked(ops.pack_weights_fwd(w).to(dtype).to(DEV), blocked, H, W, cin, cout, dtype)
+    y = ops.conv_igemm(ops.to_nhwc(x, dtype).to(DEV), wp, b.to(DEV), flags=flags)
     assert_close(ops.from_nhwc(y), ref, dtype, 9 * cin, f"conv fwd {case} flags={flags}")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_igemm_dgrad_mask_accum(dtype, case):
+@pytest.mark.parametrize("blocked", [False, True])
+def test_conv_igemm_dgrad_mask_accum(dtype, case, blocked):
     cin, cout, H, W = case
     w = rnd((cout, cin, 3, 3), 21, -1, 1) * (2.0 / (9 * cin)) ** 0.5
     dy = rnd((1, cout, H, W), 22)
@@ -112,7 +134,8 @@ def test_conv_igemm_dgrad_mask_accum(dtype, case):
     F.conv2d(xr, wq, None, padding=1).backward(dyq)
     ref = xr.grad * (zq > 0).float() + pq
     out = ops.to_nhwc(prev, dtype).to(DEV)
-    ops.conv_igemm(ops.to_nhwc(dy, dtype).to(DEV), ops.pack_weights_bwd(w).to(dtype).to(DEV), None,
+    wp = _maybe_blocked(ops.pack_weights_bwd(w).to(dtype).to(DEV), blocked, H, W, cout, cin, dtype)
+    ops.conv_igemm(ops.to_nhwc(dy, dtype).to(DEV), wp, None,
                    ref=ops.to_nhwc(zref, dtype).to(DEV), out=out, flags=ops.MASK | ops.ACCUM)
     assert_close(ops.from_nhwc(out), ref, dtype, 9 * cout, f"dgrad {case}")
 

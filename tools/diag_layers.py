@@ -17,10 +17,11 @@ model = core_model.StyleContentModel(m["style_layers"], m["content_layers"]).to(
 content, style = case.images()
 model.set_targets(style.to(DEV), content.to(DEV))
 x = case.tensor("x0").to(DEV).requires_grad_(True)
-state, work = ops.lbfgs_alloc(x.numel(), 100, DEV)
+compact = (sys.argv[3] != "0") if len(sys.argv) > 3 else True
+state, work = ops.lbfgs_alloc(x.numel(), 100, DEV, compact=compact)
 for step in range(nsteps):
     model.loss_and_grad(x, m["style_w"], m["content_w"])
-    ops.lbfgs_step(x.detach(), x.grad, state, work, 100, min(step, 100), 1.0)
+    ops.lbfgs_step(x.detach(), x.grad, state, work, 100, min(step, 100), 1.0, compact=compact)
 model.loss_and_grad(x, m["style_w"], m["content_w"])
 torch.cuda.synchronize()
 eng = next(iter(model._engines.values()))
