@@ -48,11 +48,16 @@ __device__ unsigned long long g_stv_stamps[8 * 16384];
 
 namespace {
 
-template <typename T, int TH_, int BN_, int WM_, int WN_, int TAPS_>
+template <typename T, int TH_, int BN_, int WM_, int WN_, int TAPS_, int KS_ = 1>
 struct Cfg {
   using Elem = T;
   static constexpr int TH = TH_, BN = BN_, WM = WM_, WN = WN_, TAPS = TAPS_;
-  static constexpr int NWAVES = WM_ * WN_;           // 4 (one wave per SIMD) or 8 (two per SIMD)
+  static constexpr int NWAVES = WM_ * WN_;           // waves of one K group
+  // KS = 2: two wave groups share the output tile and split K between them (group g owns the
+  // K-stages c = g mod 2, in LDS buffers of its own); their accumulators meet in the LDS C tile.
+  // A layer too small to give every CU two workgroups gets its second wave per SIMD this way.
+  static constexpr int KS = KS_;
+  static constexpr int GT = 64 * NWAVES;             // threads of one K group
   static constexpr int TW = 32;
   static constexpr int KB = 32;                      // K bytes per pixel per stage
   static constexpr int CK = KB / (int)sizeof(T);     // channels per stage
@@ -68,21 +73,22 @@ struct Cfg {
   static constexpr int MT = TH / WM;                 // image rows (32-pixel MFMA row blocks) per wave
   static constexpr int NT = BN / WN / 32;
   static constexpr int AROWS = MT + 2 * HALO;        // halo-tile rows a wave reads per horizontal tap
-  static constexpr int THREADS = 64 * NWAVES;
+  static constexpr int THREADS = GT * KS;
   // staging slots (16-byte vectors): the halo tile padded to whole waves, then the weight rows,
   // so that every (iteration, wave) pair reads from exactly one of the two tensors
   static constexpr int IN_VECS = IN_PIX * 2;
   static constexpr int IN_SLOTS = (IN_VECS + 63) / 64 * 64;
   static constexpr int W_VECS = W_ROWS * 2;
   static constexpr int SLOTS = IN_SLOTS + W_VECS;
-  static constexpr int ITERS = (SLOTS + THREADS - 1) / THREADS;
+  static constexpr int ITERS = (SLOTS + GT - 1) / GT;
   // idle staging lanes park their write in row padding
-  static constexpr int PARK_ROWS = (IN_PIX + W_ROWS < THREADS) ? IN_PIX + W_ROWS : THREADS;
+  static constexpr int PARK_ROWS = (IN_PIX + W_ROWS < GT) ? IN_PIX + W_ROWS : GT;
   static constexpr int BM = TH * TW;
   static constexpr int CS = BN + 4;                  // C-tile pitch in floats
   static constexpr int C_BYTES = BM * CS * 4;
-  static constexpr int LDS_BYTES = (2 * STAGE_BYTES > C_BYTES) ? 2 * STAGE_BYTES : C_BYTES;
-  static_assert(NWAVES == 4 || NWAVES == 8, "4 or 8 waves per workgroup");
+  static constexpr int LDS_BYTES = (2 * KS * STAGE_BYTES > C_BYTES) ? 2 * KS * STAGE_BYTES : C_BYTES;
+  static_assert(NWAVES * KS == 4 || NWAVES * KS == 8, "4 or 8 waves per workgroup");
+  static_assert(KS == 1 || KS == 2, "K split");
   static_assert(TH % WM == 0 && BN % (WN * 32) == 0, "tile split");
   static_assert(STAGE_BYTES % 16 == 0, "16-byte aligned stages");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -123,7 +129,10 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & (C::NWAVES - 1);   // scalar: selects descriptors below
+  const int wave_wg = __builtin_amdgcn_readfirstlane(tid >> 6) & (C::NWAVES * C::KS - 1);   // scalar
+  const int grp = wave_wg / C::NWAVES;               // K group
+  const int wave = wave_wg % C::NWAVES;              // wave within the group: selects descriptors below
+  const int gtid = tid & (C::GT - 1);
   const int wm = wave / C::WN, wn = wave % C::WN;
   const int r = lane & 31, h = lane >> 5;
 
@@ -161,11 +170,11 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
   const uint32_t relu_enable = relu_in ? 0xFFFFFFFFu : 0u;
   uint32_t s_off[C::ITERS];
   int s_lds[C::ITERS];
-  auto slot_is_input = [&](int it) { return (it * C::THREADS + wave * 64) < C::IN_SLOTS; };   // wave-uniform
+  auto slot_is_input = [&](int it) { return (it * C::GT + wave * 64) < C::IN_SLOTS; };   // wave-uniform
 #pragma unroll
   for (int it = 0; it < C::ITERS; ++it) {
-    const int v = it * C::THREADS + tid;
-    const int park = (tid % C::PARK_ROWS) * C::ROWB + C::KB;
+    const int v = it * C::GT + gtid;
+    const int park = (gtid % C::PARK_ROWS) * C::ROWB + C::KB;
     if (slot_is_input(it)) {
       const int pix = v >> 1, half = v & 1;
       const int py = pix / C::IN_W, px = pix - py * C::IN_W;
@@ -199,6 +208,13 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<T*>(in ? xin : wgt), 0, live ? (in ? x_bytes : w_bytes) : 0, 0x00020000);
     sreg[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, s_off[k] + (uint32_t)(stage * (in ? C::KB : w_stride)), 0, 0);
+  };
+  // group g walks the K-stages g, g + KS, ...: `l` counts its own stages (every group runs the
+  // same number of rounds so that the workgroup barriers match; a round past the end stages zeros)
+  const int nrounds = (nchunks + C::KS - 1) / C::KS;
+  auto round_load = [&](int k, int l, bool enable) {
+    const int stage = l * C::KS + grp;
+    slot_load(k, stage, enable && stage < nchunks);
   };
   // branch-free: ReLU-on-load clears elements whose sign bit is set under a wave-uniform enable mask
   auto slot_write = [&](char* buf, int k) {
@@ -264,7 +280,7 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
       for (int k = step * PER; k < (step + 1) * PER; ++k)
         if (k < C::ITERS) {
           if (!(STV_DIAG & 2)) slot_write(nxt, k);
-          slot_load(k, c + 2, (c + 2) < nchunks && !(STV_DIAG & 1));
+          round_load(k, c + 2, !(STV_DIAG & 1));
         }
     }
     __syncthreads();
@@ -272,23 +288,23 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
 
   // prologue: stage 0 -> LDS buffer 0, stage 1 in flight
 #pragma unroll
-  for (int k = 0; k < C::ITERS; ++k) slot_load(k, 0, true);
+  for (int k = 0; k < C::ITERS; ++k) round_load(k, 0, true);
+  char* const buf0 = smem + grp * (2 * C::STAGE_BYTES);
+  char* const buf1 = buf0 + C::STAGE_BYTES;
 #pragma unroll
   for (int k = 0; k < C::ITERS; ++k) {
-    slot_write(smem, k);
-    slot_load(k, 1, 1 < nchunks);
+    slot_write(buf0, k);
+    round_load(k, 1, true);
   }
   __syncthreads();
   STV_STAMP(1);
 
-  char* const buf0 = smem;
-  char* const buf1 = smem + C::STAGE_BYTES;
   int c = 0;
-  for (; c + 1 < nchunks; c += 2) {
+  for (; c + 1 < nrounds; c += 2) {
     run_stage(buf0, buf1, c);
     run_stage(buf1, buf0, c + 1);
   }
-  if (c < nchunks) run_stage(buf0, buf1, c);
+  if (c < nrounds) run_stage(buf0, buf1, c);
   STV_STAMP(2);
 
   // ---- epilogue: accumulators -> LDS C tile (fp32) -> 16-byte vector stores ----
@@ -317,16 +333,29 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
   }
 
   float* cs = reinterpret_cast<float*>(smem);
+  // mode 0: tile = accumulators; mode 1: accumulators += tile (over this lane's share of the tile)
+  auto c_tile = [&](auto mode) {
 #pragma unroll
-  for (int mt = 0; mt < C::MT; ++mt)
+    for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < C::NT; ++nt)
+      for (int nt = 0; nt < C::NT; ++nt)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = (wm * C::MT + mt) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        const int col = wn * (C::NT * 32) + nt * 32 + r;
-        cs[row * C::CS + col] = acc[mt][nt][i];
-      }
+        for (int i = 0; i < 16; ++i) {
+          const int row = (wm * C::MT + mt) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          const int col = wn * (C::NT * 32) + nt * 32 + r;
+          if (decltype(mode)::value == 0) cs[row * C::CS + col] = acc[mt][nt][i];
+          else acc[mt][nt][i] += cs[row * C::CS + col];
+        }
+  };
+  using Put = std::integral_constant<int, 0>;
+  using Add = std::integral_constant<int, 1>;
+  if (C::KS == 2) {               // the second K group hands its partial sums over through the tile
+    if (grp == 1) c_tile(Put{});
+    __syncthreads();
+    if (grp == 0) c_tile(Add{});
+    __syncthreads();
+  }
+  if (grp == 0) c_tile(Put{});
   __syncthreads();
   STV_STAMP(3);
 
@@ -420,7 +449,9 @@ int choose_cfg(int H, int W, int cin, int cout, int elem_bytes) {
   // Pick the tile that finishes first: waves of workgroups over 256 CUs x work per workgroup
   // / relative efficiency of the tile (measured with tools/conv_sweep.py).
   static const int th[4] = {8, 8, 4, 4}, bn[4] = {128, 64, 128, 64};
-  static const float eff[4] = {1.0f, 0.89f, 0.68f, 0.70f};
+  static const float eff_tab[2][4] = {{1.0f, 0.84f, 0.72f, 0.82f},    // cin >= 128
+                                      {1.0f, 0.84f, 0.72f, 0.91f}};   // short K: the 4-row tile holds up better
+  const float* eff = eff_tab[cin <= 64 ? 1 : 0];
   int best = 0;
   float best_cost = 3.4e38f;
   for (int i = 0; i < 4; ++i) {
@@ -434,6 +465,7 @@ int choose_cfg(int H, int W, int cin, int cout, int elem_bytes) {
     const int f = atoi(force);
     if (f >= 0 && f < 4 && !(cout <= 64 && bn[f] == 128)) best = f;
     if (f == 4 && cout > 64) best = 4;   // experimental: 8x128 with waves as 2(M) x 4(N)
+    if (f == 5) best = 5;
   }
   return best;
 }
@@ -455,6 +487,7 @@ int launch_typed(const ConvArgs& a, hipStream_t st) {
     case 1: return launch_cfg<Cfg<T, 8, 64, 4, 2, TAPS>>(a, st);    // 64 px x 32 couts per wave
     case 2: return launch_cfg<Cfg<T, 4, 128, 1, 4, TAPS>>(a, st);
     case 4: return launch_cfg<Cfg<T, 8, 128, 2, 4, TAPS>>(a, st);
+    case 5: return launch_cfg<Cfg<T, 4, 64, 2, 2, TAPS, 2>>(a, st);   // small layers: K split over two wave groups
     default: return launch_cfg<Cfg<T, 4, 64, 2, 2, TAPS>>(a, st);
   }
 }

@@ -121,6 +121,31 @@ def test_conv_igemm_forward(dtype, case, flags, blocked):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("case", [(128, 128, 21, 70), (64, 64, 9, 33), (48, 136, 12, 40), (512, 128, 8, 8)])
+def test_conv_igemm_every_tile_config(dtype, cfg, case, monkeypatch):
+    """Each tile shape / wave layout / K split (forced with STV_CONV_CFG) on full, ragged and odd-K shapes."""
+    cin, cout, H, W = case
+    if cout <= 64 and cfg in (0, 2, 4):
+        pytest.skip("128-channel tiles need more than 64 output channels")
+    monkeypatch.setenv("STV_CONV_CFG", str(cfg))
+    x = rnd((1, cin, H, W), 41)
+    w = rnd((cout, cin, 3, 3), 42, -1, 1) * (2.0 / (9 * cin)) ** 0.5
+    b = rnd((cout,), 43, -0.2, 0.2)
+    z = rnd((1, cout, H, W), 44)
+    prev = rnd((1, cout, H, W), 45)
+    ref = F.relu(F.conv2d(F.relu(q(x, dtype)), q(w, dtype), b, padding=1))
+    wp = ops.block_weights(ops.pack_weights_fwd(w).to(dtype).to(DEV))
+    y = ops.conv_igemm(ops.to_nhwc(x, dtype).to(DEV), wp, b.to(DEV), flags=ops.RELU_IN | ops.RELU_OUT)
+    assert_close(ops.from_nhwc(y), ref, dtype, 9 * cin, f"cfg {cfg} fwd {case}")
+    ref2 = F.conv2d(q(x, dtype), q(w, dtype), None, padding=1) * (q(z, dtype) > 0).float() + q(prev, dtype)
+    out = ops.to_nhwc(prev, dtype).to(DEV)
+    ops.conv_igemm(ops.to_nhwc(x, dtype).to(DEV), wp, None, ref=ops.to_nhwc(z, dtype).to(DEV), out=out,
+                   flags=ops.MASK | ops.ACCUM)
+    assert_close(ops.from_nhwc(out), ref2, dtype, 9 * cin, f"cfg {cfg} mask+accum {case}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", CONV_CASES)
 @pytest.mark.parametrize("blocked", [False, True])
 def test_conv_igemm_dgrad_mask_accum(dtype, case, blocked):

@@ -5,26 +5,28 @@ import torch
 from style_transfer_visualizer_amd import ops
 
 dev = torch.device("cuda")
-shapes = [(1024, 1024, 64, 64), (512, 512, 64, 128), (512, 512, 128, 128), (256, 256, 128, 256), (256, 256, 256, 256),
-          (128, 128, 256, 512), (128, 128, 512, 512), (64, 64, 512, 512), (32, 32, 512, 512)]
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 1024     # image size: VGG19 forward and dgrad shapes up to conv5_1
+shapes = [(S, S, 64, 64), (S // 2, S // 2, 64, 128), (S // 2, S // 2, 128, 64), (S // 2, S // 2, 128, 128),
+          (S // 4, S // 4, 128, 256), (S // 4, S // 4, 256, 128), (S // 4, S // 4, 256, 256),
+          (S // 8, S // 8, 256, 512), (S // 8, S // 8, 512, 256), (S // 8, S // 8, 512, 512), (S // 16, S // 16, 512, 512)]
 dtype = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] == "bf16") else torch.float32
-names = ["8x128", "8x64", "4x128", "4x64"]
+names = ["8x128", "8x64", "4x128", "4x64", "8x128/2x4", "4x64/K2"]
 for (H, W, cin, cout) in shapes:
     x = torch.randn(H, W, cin, device=dev).to(dtype)
-    w = (torch.randn(9, cout, cin, device=dev) * 0.02).to(dtype)
+    w = ops.block_weights((torch.randn(9, cout, cin, device=dev) * 0.02).to(dtype))
     b = torch.zeros(cout, device=dev)
     y = torch.empty(H, W, cout, device=dev, dtype=dtype)
     row = []
-    for cfg in range(4):
+    for cfg in range(6):
         os.environ["STV_CONV_CFG"] = str(cfg)
-        if cout <= 64 and cfg in (0, 2):
+        if cout <= 64 and cfg in (0, 2, 4):
             row.append("   -  ")
             continue
         for _ in range(3):
             ops.conv_igemm(x, w, b, out=y, flags=ops.RELU_OUT)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        n = 20
+        n = 50
         e0.record()
         for _ in range(n):
             ops.conv_igemm(x, w, b, out=y, flags=ops.RELU_OUT)
