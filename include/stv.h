@@ -68,6 +68,18 @@ int stv_conv_first_fwd(const float* x_nchw, const float* wf, const float* bias,
 int stv_conv_first_dgrad(const void* dy, const float* wf, float* dx_nchw,
                          int H, int W, int cin, int cout, int dtype, void* stream);
 
+/* The same two calls for frozen weights: stv_conv_first_pack() writes the
+ * kernel-side packing of `wf` (forward order, then flipped taps for dgrad) into
+ * a caller-owned buffer of stv_conv_first_packed_bytes(cin, cout) bytes, once;
+ * the *_packed entries then skip the per-call repack. */
+size_t stv_conv_first_packed_bytes(int cin, int cout);
+int stv_conv_first_pack(const float* wf, float* packed, int cin, int cout, void* stream);
+int stv_conv_first_fwd_packed(const float* x_nchw, const float* packed, const float* bias,
+                              void* y, int H, int W, int cin, int cout, int dtype,
+                              void* stream);
+int stv_conv_first_dgrad_packed(const void* dy, const float* packed, float* dx_nchw,
+                                int H, int W, int cin, int cout, int dtype, void* stream);
+
 /* Implicit-GEMM 3x3 conv, pad 1, stride 1, NHWC.  `w` is [taps][cout][cin] in
  * `dtype` (K-contiguous rows); bias fp32[cout] or NULL.  taps = 9 (3x3) or 1
  * (1x1, used for the Gram backward product).  flags: RELU_IN, RELU_OUT,
@@ -163,6 +175,8 @@ enum {
   STV_OP_GRAM_FINISH, STV_OP_CONTENT_LOSS, STV_OP_CONTENT_GRAD, STV_OP_LOSS_COMBINE,
   STV_OP_MEMSET
 };
+/* Operands follow the direct entry points' argument order (inputs p0.., outputs q0..).
+ * CONV_FIRST_FWD takes the optional stv_conv_first_pack buffer in p3, CONV_FIRST_DGRAD in p2. */
 typedef struct {
   int32_t op, dtype, flags, taps;
   int32_t H, W, cin, cout;

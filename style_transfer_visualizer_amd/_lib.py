@@ -46,6 +46,10 @@ SIGNATURES = {
     "stv_gram_loss_parts": (c_int, [c_int]),
     "stv_conv_first_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "stv_conv_first_dgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "stv_conv_first_packed_bytes": (c_size_t, [c_int, c_int]),
+    "stv_conv_first_pack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "stv_conv_first_fwd_packed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "stv_conv_first_dgrad_packed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "stv_conv_igemm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "stv_conv_config": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "stv_maxpool_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -281,13 +281,18 @@ float* first_scratch() {
   return p;
 }
 
+// `packed` (optional): the caller's buffer from stv_conv_first_pack - no per-call repack
 template <typename T>
-int fwd_typed(const float* x, const float* wf, const float* bias, void* y, int H, int W, int cin,
-              int cout, hipStream_t st) {
+int fwd_typed(const float* x, const float* wf, const float* packed, const float* bias, void* y, int H, int W,
+              int cin, int cout, hipStream_t st) {
   if (cin == 3 && cout == 64) {
-    float* wt = first_scratch();
-    if (!wt) return STV_ERR_ALLOC;
-    hipLaunchKernelGGL(repack_first_weights, dim3(7), dim3(256), 0, st, wf, wt, 0);
+    const float* wt = packed;
+    if (!wt) {
+      float* scratch = first_scratch();
+      if (!scratch) return STV_ERR_ALLOC;
+      hipLaunchKernelGGL(repack_first_weights, dim3(7), dim3(256), 0, st, wf, scratch, 0);
+      wt = scratch;
+    }
     const int tiles = ceil_div(W, FT) * ceil_div(H, FT);
     hipLaunchKernelGGL(conv_first_fwd_c64<T>, dim3(tiles), dim3(256), 0, st, x, wt, bias, static_cast<T*>(y), H, W);
     STV_CHECK_LAUNCH();
@@ -308,13 +313,16 @@ int fwd_typed(const float* x, const float* wf, const float* bias, void* y, int H
   return STV_OK;
 }
 template <typename T>
-int dgrad_typed(const void* dy, const float* wf, float* dx, int H, int W, int cin, int cout,
+int dgrad_typed(const void* dy, const float* wf, const float* packed, float* dx, int H, int W, int cin, int cout,
                 hipStream_t st) {
   if (cin == 3 && cout == 64) {
-    float* wt = first_scratch();
-    if (!wt) return STV_ERR_ALLOC;
-    float* wd = wt + 1728;
-    hipLaunchKernelGGL(repack_first_weights, dim3(7), dim3(256), 0, st, wf, wd, 1);
+    const float* wd = packed ? packed + 1728 : nullptr;
+    if (!wd) {
+      float* scratch = first_scratch();
+      if (!scratch) return STV_ERR_ALLOC;
+      hipLaunchKernelGGL(repack_first_weights, dim3(7), dim3(256), 0, st, wf, scratch + 1728, 1);
+      wd = scratch + 1728;
+    }
     const int tiles = ceil_div(W, FT) * ceil_div(H, FT);
     const size_t lds = (size_t)FH * FH * (64 * sizeof(T) + 16);
     static bool attr = false;
@@ -346,12 +354,49 @@ int dgrad_typed(const void* dy, const float* wf, float* dx, int H, int W, int ci
 
 }  // namespace
 
+extern "C" size_t stv_conv_first_packed_bytes(int cin, int cout) {
+  return (size_t)2 * 9 * (size_t)(cin > 0 ? cin : 0) * (size_t)(cout > 0 ? cout : 0) * sizeof(float);
+}
+
+extern "C" int stv_conv_first_pack(const float* wf, float* packed, int cin, int cout, void* stream) {
+  if (!wf || !packed || cin <= 0 || cout <= 0) return STV_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (cin == 3 && cout == 64) {
+    hipLaunchKernelGGL(repack_first_weights, dim3(7), dim3(256), 0, st, wf, packed, 0);
+    hipLaunchKernelGGL(repack_first_weights, dim3(7), dim3(256), 0, st, wf, packed + 1728, 1);
+    STV_CHECK_LAUNCH();
+    return STV_OK;
+  }
+  // the other shapes read the weights as they are: the packed form is a copy
+  if (hipMemcpyAsync(packed, wf, (size_t)9 * cin * cout * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+    return STV_ERR_LAUNCH;
+  return STV_OK;
+}
+
+extern "C" int stv_conv_first_fwd_packed(const float* x_nchw, const float* packed, const float* bias, void* y,
+                                         int H, int W, int cin, int cout, int dtype, void* stream) {
+  if (!x_nchw || !packed || !y || H <= 0 || W <= 0 || cin <= 0 || cout <= 0) return STV_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == STV_F32) return fwd_typed<float>(x_nchw, packed, packed, bias, y, H, W, cin, cout, st);
+  if (dtype == STV_BF16) return fwd_typed<bf16_t>(x_nchw, packed, packed, bias, y, H, W, cin, cout, st);
+  return STV_ERR_ARG;
+}
+
+extern "C" int stv_conv_first_dgrad_packed(const void* dy, const float* packed, float* dx_nchw, int H, int W,
+                                           int cin, int cout, int dtype, void* stream) {
+  if (!dy || !packed || !dx_nchw || H <= 0 || W <= 0 || cin <= 0 || cout <= 0) return STV_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == STV_F32) return dgrad_typed<float>(dy, packed, packed, dx_nchw, H, W, cin, cout, st);
+  if (dtype == STV_BF16) return dgrad_typed<bf16_t>(dy, packed, packed, dx_nchw, H, W, cin, cout, st);
+  return STV_ERR_ARG;
+}
+
 extern "C" int stv_conv_first_fwd(const float* x_nchw, const float* wf, const float* bias, void* y,
                                   int H, int W, int cin, int cout, int dtype, void* stream) {
   if (!x_nchw || !wf || !y || H <= 0 || W <= 0 || cin <= 0 || cout <= 0) return STV_ERR_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (dtype == STV_F32) return fwd_typed<float>(x_nchw, wf, bias, y, H, W, cin, cout, st);
-  if (dtype == STV_BF16) return fwd_typed<bf16_t>(x_nchw, wf, bias, y, H, W, cin, cout, st);
+  if (dtype == STV_F32) return fwd_typed<float>(x_nchw, wf, nullptr, bias, y, H, W, cin, cout, st);
+  if (dtype == STV_BF16) return fwd_typed<bf16_t>(x_nchw, wf, nullptr, bias, y, H, W, cin, cout, st);
   return STV_ERR_ARG;
 }
 
@@ -359,7 +404,7 @@ extern "C" int stv_conv_first_dgrad(const void* dy, const float* wf, float* dx_n
                                     int cin, int cout, int dtype, void* stream) {
   if (!dy || !wf || !dx_nchw || H <= 0 || W <= 0 || cin <= 0 || cout <= 0) return STV_ERR_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (dtype == STV_F32) return dgrad_typed<float>(dy, wf, dx_nchw, H, W, cin, cout, st);
-  if (dtype == STV_BF16) return dgrad_typed<bf16_t>(dy, wf, dx_nchw, H, W, cin, cout, st);
+  if (dtype == STV_F32) return dgrad_typed<float>(dy, wf, nullptr, dx_nchw, H, W, cin, cout, st);
+  if (dtype == STV_BF16) return dgrad_typed<bf16_t>(dy, wf, nullptr, dx_nchw, H, W, cin, cout, st);
   return STV_ERR_ARG;
 }

@@ -2,26 +2,31 @@
 //
 //   y[p][n] = sum_{tap} sum_{c} x[p + off(tap)][c] * w[tap][n][c]   (+bias, epilogue)
 //
-// M = pixels, N = output channels, K = taps * Cin.  A workgroup owns a
-// TH x 32 pixel tile and BN output channels.  Per K-stage (32 bytes of K per
-// pixel: 16 bf16 / 8 fp32 channels) it stages the (TH+2) x 34 halo tile of the
-// input and the [taps][BN] weight rows for that channel slice in LDS, then
-// every wave walks the 9 taps as shifted windows of the same LDS tile, so the
-// input is fetched ~1.3x (halo) instead of 9x.  Global loads for stage s+1 are
-// issued (raw buffer loads: the hardware range check zero-fills halo / channel
-// padding, so there is no branch or select in front of the data) before the
-// MFMAs of stage s; their ds_writes into the other LDS buffer are spread over
-// the later taps' MFMA groups, so neither the HBM/L2 latency nor the LDS write
-// sits on the critical path.  One barrier per stage.
+// M = pixels, N = output channels, K = taps * Cin.  A workgroup owns a TH x 32 pixel tile and BN
+// output channels.  Per K-stage (32 bytes of K per pixel: 16 bf16 / 8 fp32 channels) the
+// (TH+2) x 34 halo tile of the input and the [taps][BN] weight rows of that channel slice sit in
+// LDS, and every wave walks the 9 taps as shifted windows of the same LDS tile, so the input is
+// fetched ~1.3x (halo) instead of 9x.
+//
+// Staging is LDS-DMA (buffer_load ... lds): no VGPR round trip and no ds_write - the LDS write
+// port was the busiest unit of the register-staged version of this kernel.  One wave-instruction
+// moves 64 x 16 B to 1 KiB of consecutive LDS, so the LDS image is lane-linear with a 32-byte row
+// pitch; bank conflicts are avoided by an XOR swizzle of the two 16-byte halves of a row
+// (half ^= bit 3 of the row index), applied on the source address when the row is fetched and
+// again when a fragment is read.  Out-of-range sources (halo pixels outside the image, channel
+// rows past Cout, stages past the end of K) are zero-filled by the buffer range check.  A ring of
+// three LDS buffers keeps the fetch two K-stages ahead of the MFMAs; every wave issues the same
+// number of DMAs per stage, so a counted s_waitcnt vmcnt(N) retires exactly one stage at each
+// barrier (one barrier per stage).
 //
 // MFMA shapes: bf16 -> v_mfma_f32_32x32x16_bf16 (lane (r,h) holds k = 8h..8h+7),
 //              fp32 -> v_mfma_f32_32x32x2_f32 x4 with lane (r,h) holding
 //              k = 4h..4h+3 (any k permutation is fine as long as A and B agree).
-// A 32-pixel MFMA row block is one 32-wide image row segment, so the 16-lane
-// groups of ds_read_b128 hit 16 distinct 16-byte slots (row pitch 48 B).
+// ReLU-on-load (STV_RELU_IN) is one packed integer max per fragment dword (a negative bf16 / fp32
+// is a negative integer), against a scalar that is 0 or INT_MIN - branch-free.
 //
-// The same kernel computes the input gradient (dgrad) when handed the flipped,
-// transposed weights, and the Gram backward product dF = F * S as a 1x1 conv.
+// The same kernel computes the input gradient (dgrad) when handed the flipped, transposed
+// weights, and the Gram backward product dF = F * S as a 1x1 conv.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -59,38 +64,37 @@ struct Cfg {
   static constexpr int KS = KS_;
   static constexpr int GT = 64 * NWAVES;             // threads of one K group
   static constexpr int TW = 32;
-  static constexpr int KB = 32;                      // K bytes per pixel per stage
+  static constexpr int KB = 32;                      // K bytes per pixel per stage = LDS row pitch
   static constexpr int CK = KB / (int)sizeof(T);     // channels per stage
-  static constexpr int ROWB = KB + 16;               // padded LDS row pitch
   static constexpr int HALO = (TAPS == 9) ? 1 : 0;
   static constexpr int ND = (TAPS == 9) ? 3 : 1;     // taps per axis
   static constexpr int IN_H = TH + 2 * HALO, IN_W = TW + 2 * HALO;
   static constexpr int IN_PIX = IN_H * IN_W;
-  static constexpr int IN_BYTES = IN_PIX * ROWB;
   static constexpr int W_ROWS = TAPS * BN;
-  static constexpr int W_BYTES = W_ROWS * ROWB;
-  static constexpr int STAGE_BYTES = IN_BYTES + W_BYTES;
   static constexpr int MT = TH / WM;                 // image rows (32-pixel MFMA row blocks) per wave
   static constexpr int NT = BN / WN / 32;
   static constexpr int AROWS = MT + 2 * HALO;        // halo-tile rows a wave reads per horizontal tap
   static constexpr int THREADS = GT * KS;
-  // staging slots (16-byte vectors): the halo tile padded to whole waves, then the weight rows,
-  // so that every (iteration, wave) pair reads from exactly one of the two tensors
-  static constexpr int IN_VECS = IN_PIX * 2;
-  static constexpr int IN_SLOTS = (IN_VECS + 63) / 64 * 64;
-  static constexpr int W_VECS = W_ROWS * 2;
-  static constexpr int SLOTS = IN_SLOTS + W_VECS;
-  static constexpr int ITERS = (SLOTS + GT - 1) / GT;
-  // idle staging lanes park their write in row padding
-  static constexpr int PARK_ROWS = (IN_PIX + W_ROWS < GT) ? IN_PIX + W_ROWS : GT;
+  // DMA pieces (one wave-instruction = 64 slots of 16 B = 32 rows): the halo tile rounded up to
+  // whole pieces, then the weight rows; every wave of a group issues PPW pieces per stage (the
+  // surplus ones of the last round are aimed at a spare KiB with a zero-record descriptor)
+  static constexpr int IN_PIECES = (IN_PIX * 2 + 63) / 64;
+  static constexpr int W_PIECES = (W_ROWS * 2 + 63) / 64;
+  static constexpr int PIECES = IN_PIECES + W_PIECES;
+  static constexpr int PPW = (PIECES + NWAVES - 1) / NWAVES;
+  static constexpr int IN_BYTES = IN_PIECES * 1024;
+  static constexpr int SPARE_OFF = PIECES * 1024;
+  static constexpr int STAGE_BYTES = SPARE_OFF + 1024;
+  static constexpr int NBUF = 3;                     // LDS ring: the DMA runs two stages ahead
   static constexpr int BM = TH * TW;
   static constexpr int CS = BN + 4;                  // C-tile pitch in floats
   static constexpr int C_BYTES = BM * CS * 4;
-  static constexpr int LDS_BYTES = (2 * KS * STAGE_BYTES > C_BYTES) ? 2 * KS * STAGE_BYTES : C_BYTES;
+  static constexpr int RING_BYTES = NBUF * KS * STAGE_BYTES;
+  static constexpr int LDS_BYTES = (RING_BYTES > C_BYTES) ? RING_BYTES : C_BYTES;
   static_assert(NWAVES * KS == 4 || NWAVES * KS == 8, "4 or 8 waves per workgroup");
   static_assert(KS == 1 || KS == 2, "K split");
   static_assert(TH % WM == 0 && BN % (WN * 32) == 0, "tile split");
-  static_assert(STAGE_BYTES % 16 == 0, "16-byte aligned stages");
+  static_assert(BN % 16 == 0, "swizzle period");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
@@ -120,10 +124,29 @@ __device__ __forceinline__ void mma<float>(const f32x4& a, const f32x4& b, f32x1
   for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
 }
 
+// ReLU of a fragment as a packed integer max against `floor` (0: ReLU on, INT_MIN pattern: off)
+__device__ __forceinline__ bf16x8v relu_frag(bf16x8v v, uint32_t floor) {
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const s16x8 lo = (s16x8)((short)(floor & 0xFFFFu));                  // splat
+  return __builtin_bit_cast(bf16x8v, __builtin_elementwise_max(__builtin_bit_cast(s16x8, v), lo));
+}
+__device__ __forceinline__ f32x4 relu_frag(f32x4 v, uint32_t floor) {
+  typedef __attribute__((ext_vector_type(4))) int i32x4;
+  const i32x4 lo = (i32x4)((int)floor);
+  return __builtin_bit_cast(f32x4, __builtin_elementwise_max(__builtin_bit_cast(i32x4, v), lo));
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 template <typename C>
 __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (LDS address-space casts are device-only)
   using T = typename C::Elem;
   using FragT = typename Frag<T>::type;
+  using lds_ptr = __attribute__((address_space(3))) void*;
   constexpr int kVec = elem_traits<T>::kVec;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -131,8 +154,7 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
   const int lane = tid & 63;
   const int wave_wg = __builtin_amdgcn_readfirstlane(tid >> 6) & (C::NWAVES * C::KS - 1);   // scalar
   const int grp = wave_wg / C::NWAVES;               // K group
-  const int wave = wave_wg % C::NWAVES;              // wave within the group: selects descriptors below
-  const int gtid = tid & (C::GT - 1);
+  const int wave = wave_wg % C::NWAVES;              // wave within the group
   const int wm = wave / C::WN, wn = wave % C::WN;
   const int r = lane & 31, h = lane >> 5;
 
@@ -144,9 +166,10 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
 
   const T* __restrict__ xin = static_cast<const T*>(a.x);
   const T* __restrict__ wgt = static_cast<const T*>(a.w);
-  const bool relu_in = (a.flags & STV_RELU_IN) != 0;
   const bool w_blocked = (a.flags & STV_W_BLOCKED) != 0;
   const int nchunks = a.cin / C::CK;
+  // ReLU-on-load floor: integer max with 0 clears negative elements, with INT_MIN it is the identity
+  const uint32_t relu_floor = (a.flags & STV_RELU_IN) ? 0u : (sizeof(T) == 2 ? 0x80008000u : 0x80000000u);
   STV_STAMP(0);
   // this thread's slice of the bias (all its output vectors share one channel group): requested
   // first, a global round trip is ~2 us on a busy chip and nothing else in the epilogue waits
@@ -163,62 +186,52 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
     for (int e = 0; e < 4; ++e) bias_v[q][e] = __uint_as_float(t[e]);
   }
 
-  // ---- per-thread staging slots: byte offsets, OOB -> zero fill by the buffer range check ----
+  // ---- DMA pieces of this wave: per-lane source byte offsets (out of range -> zero fill) ----
   constexpr uint32_t kOob = 0x80000000u;   // >= num_records for every tensor this kernel accepts
   const int x_bytes = a.H * a.W * a.cin * (int)sizeof(T);
   const int w_bytes = C::TAPS * a.cout * a.cin * (int)sizeof(T);
-  const uint32_t relu_enable = relu_in ? 0xFFFFFFFFu : 0u;
-  uint32_t s_off[C::ITERS];
-  int s_lds[C::ITERS];
-  auto slot_is_input = [&](int it) { return (it * C::GT + wave * 64) < C::IN_SLOTS; };   // wave-uniform
-#pragma unroll
-  for (int it = 0; it < C::ITERS; ++it) {
-    const int v = it * C::GT + gtid;
-    const int park = (gtid % C::PARK_ROWS) * C::ROWB + C::KB;
-    if (slot_is_input(it)) {
-      const int pix = v >> 1, half = v & 1;
-      const int py = pix / C::IN_W, px = pix - py * C::IN_W;
-      const int gy = y0 + py - C::HALO, gx = x0 + px - C::HALO;
-      const bool ok = (v < C::IN_VECS) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-      s_off[it] = ok ? (uint32_t)(((gy * a.W + gx) * a.cin + half * kVec) * (int)sizeof(T)) : kOob;
-      s_lds[it] = (v < C::IN_VECS) ? pix * C::ROWB + half * 16 : park;
-    } else {
-      const int wv = v - C::IN_SLOTS;
-      const int row = wv >> 1, half = wv & 1;
-      const int tap = row / C::BN, n = row - tap * C::BN;
-      const bool ok = (wv < C::W_VECS) && (n0 + n) < a.cout;
-      const int elem = w_blocked ? ((tap * nchunks * a.cout + n0 + n) * C::CK + half * kVec)
-                                 : ((tap * a.cout + n0 + n) * a.cin + half * kVec);
-      s_off[it] = ok ? (uint32_t)(elem * (int)sizeof(T)) : kOob;
-      s_lds[it] = (wv < C::W_VECS) ? C::IN_BYTES + row * C::ROWB + half * 16 : park;
-    }
-  }
   // bytes from one K-stage to the next: 32 along a pixel's (or plain weight row's) channels,
   // a whole [cout][CK] slab in the K-blocked weight layout
   const int w_stride = w_blocked ? a.cout * C::KB : C::KB;
-
-  // One register per slot.  In K-stage c a slot's register (holding stage c+1, loaded during
-  // stage c-1) is written to the other LDS buffer and immediately re-loaded with stage c+2, one
-  // slot per tap, so every global load has a full stage of MFMA work to land and neither the
-  // loads nor the LDS writes arrive in a burst.
-  u32x4 sreg[C::ITERS];
-  // `live` = false turns the load into an out-of-range one (zero records): no traffic, no branch
-  auto slot_load = [&](int k, int stage, bool live) {
-    const bool in = slot_is_input(k);
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<T*>(in ? xin : wgt), 0, live ? (in ? x_bytes : w_bytes) : 0, 0x00020000);
-    sreg[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, s_off[k] + (uint32_t)(stage * (in ? C::KB : w_stride)), 0, 0);
-  };
+  // piece j of this wave is piece j * NWAVES + wave of the stage: input pieces first, then weights
+  auto piece_id = [&](int j) { return j * C::NWAVES + wave; };                  // wave-uniform
+  uint32_t p_off[C::PPW];
+#pragma unroll
+  for (int j = 0; j < C::PPW; ++j) {
+    const int g = piece_id(j);
+    if (g < C::IN_PIECES) {
+      const int v = g * 64 + lane;
+      const int pix = v >> 1;
+      const int half = (v & 1) ^ ((pix >> 3) & 1);                 // swizzle on the source side
+      const int py = pix / C::IN_W, px = pix - py * C::IN_W;
+      const int gy = y0 + py - C::HALO, gx = x0 + px - C::HALO;
+      const bool ok = pix < C::IN_PIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      p_off[j] = ok ? (uint32_t)(((gy * a.W + gx) * a.cin + half * kVec) * (int)sizeof(T)) : kOob;
+    } else {
+      const int v = (g - C::IN_PIECES) * 64 + lane;
+      const int row = v >> 1;
+      const int half = (v & 1) ^ ((row >> 3) & 1);
+      const int tap = row / C::BN, nn = row - tap * C::BN;
+      const bool ok = row < C::W_ROWS && (n0 + nn) < a.cout;
+      const int elem = w_blocked ? ((tap * nchunks * a.cout + n0 + nn) * C::CK + half * kVec)
+                                 : ((tap * a.cout + n0 + nn) * a.cin + half * kVec);
+      p_off[j] = ok ? (uint32_t)(elem * (int)sizeof(T)) : kOob;
+    }
+  }
   // group g walks the K-stages g, g + KS, ...: `l` counts its own stages (every group runs the
   // same number of rounds so that the workgroup barriers match; a round past the end stages zeros)
   const int nrounds = (nchunks + C::KS - 1) / C::KS;
-  auto round_load = [&](int k, int l, bool enable) {
+  char* const ring = smem + grp * (C::NBUF * C::STAGE_BYTES);
+  // issue piece j of this wave's share of round l into ring buffer `buf`
+  auto dma = [&](int j, int l, char* buf) {
+    const int g = piece_id(j);
     const int stage = l * C::KS + grp;
-    slot_load(k, stage, enable && stage < nchunks);
-  };
-  // branch-free: ReLU-on-load clears elements whose sign bit is set under a wave-uniform enable mask
-  auto slot_write = [&](char* buf, int k) {
-    *reinterpret_cast<u32x4*>(buf + s_lds[k]) = relu16_masked<T>(sreg[k], slot_is_input(k) ? relu_enable : 0u);
+    const bool in = g < C::IN_PIECES;
+    const bool live = g < C::PIECES && stage < nchunks && !(STV_DIAG & 1);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(in ? xin : wgt), 0, live ? (in ? x_bytes : w_bytes) : 0, 0x00020000);
+    char* dst = buf + (g < C::PIECES ? g * 1024 : C::SPARE_OFF);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)dst, 16, p_off[j], stage * (in ? C::KB : w_stride), 0, 0);
   };
 
   f32x16 acc[C::MT][C::NT];
@@ -229,30 +242,40 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.0f;
 
-  // lane-constant LDS byte offsets of this lane's A / B fragment rows
-  const int a_lane = ((wm * C::MT) * C::IN_W + r) * C::ROWB + h * 16;
-  const int b_lane = C::IN_BYTES + (wn * (C::NT * 32) + r) * C::ROWB + h * 16;
+  // lane-constant LDS byte offsets of this lane's fragments inside a stage buffer.  A: one per
+  // (horizontal tap, halo row) - the swizzle bit depends on the pixel index; B: the row index is
+  // r plus multiples of 16, so one offset serves every tap
+  int a_addr[C::ND][C::AROWS];
+#pragma unroll
+  for (int dx = 0; dx < C::ND; ++dx)
+#pragma unroll
+    for (int j = 0; j < C::AROWS; ++j) {
+      const int pix = (wm * C::MT + j) * C::IN_W + dx + r;
+      a_addr[dx][j] = pix * C::KB + ((h ^ ((pix >> 3) & 1)) << 4);
+    }
+  const int b_lane = C::IN_BYTES + (wn * (C::NT * 32) + r) * C::KB + ((h ^ ((r >> 3) & 1)) << 4);
 
   constexpr int NSTEP = C::ND * C::ND;
-  constexpr int PER = (C::ITERS + NSTEP - 1) / NSTEP;
+  constexpr int PER = (C::PPW + NSTEP - 1) / NSTEP;
   // B fragments are fetched PFB steps ahead of their MFMAs: an LDS read takes ~190 cycles under
   // load, a step only MT*NT*32 of MFMA issue, so a lone wave on a SIMD needs the deeper queue
   constexpr int PFB = (C::MT * C::NT >= 4) ? 2 : 3;
 
-  // One K-stage.  The taps are walked column by column (dx outer, dy inner): the MT+2 halo-tile
-  // rows a wave needs for one dx serve all three dy, so a stage reads 3*(MT+2) A fragments
-  // instead of 9*MT.  Fragments are fetched one step ahead of the MFMAs that use them.
-  auto run_stage = [&](char* cur, char* nxt, int c) {
+  // One K-stage out of `cur`, while round l + 2 streams into `fill`.  The taps are walked column
+  // by column (dx outer, dy inner): the MT+2 halo-tile rows a wave needs for one dx serve all
+  // three dy, so a stage reads 3*(MT+2) A fragments instead of 9*MT.  Fragments are fetched ahead
+  // of the MFMAs that use them.
+  auto run_stage = [&](const char* cur, char* fill, int l) {
     FragT af[2][C::AROWS];
     FragT bf[PFB + 1][C::NT];
     auto load_a = [&](int dx, int j, int set) {
-      af[set][j] = *reinterpret_cast<const FragT*>(cur + a_lane + (j * C::IN_W + dx) * C::ROWB);
+      af[set][j] = relu_frag(*reinterpret_cast<const FragT*>(cur + a_addr[dx][j]), relu_floor);
     };
     auto load_b = [&](int step) {
       const int tap = (step % C::ND) * C::ND + step / C::ND;     // dy * 3 + dx
 #pragma unroll
       for (int nt = 0; nt < C::NT; ++nt)
-        bf[step % (PFB + 1)][nt] = *reinterpret_cast<const FragT*>(cur + b_lane + (tap * C::BN + nt * 32) * C::ROWB);
+        bf[step % (PFB + 1)][nt] = *reinterpret_cast<const FragT*>(cur + b_lane + (tap * C::BN + nt * 32) * C::KB);
     };
     load_b(0);
 #pragma unroll
@@ -269,42 +292,47 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
         for (int j = 0; j < C::AROWS; ++j)
           if ((j < (C::AROWS + 1) / 2 ? 0 : 1) == dy) load_a(dx + 1, j, (dx + 1) & 1);
       }
-      // the next step's LDS reads are issued first, then this step's MFMAs back to back
+      // the next steps' LDS reads and this step's DMAs are issued first, then the MFMAs back to back
+#pragma unroll
+      for (int k = step * PER; k < (step + 1) * PER; ++k)
+        if (k < C::PPW) dma(k, l + 2, fill);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < C::NT; ++nt) mma<T>(af[dx & 1][mt + dy], bf[step % (PFB + 1)][nt], acc[mt][nt]);
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int k = step * PER; k < (step + 1) * PER; ++k)
-        if (k < C::ITERS) {
-          if (!(STV_DIAG & 2)) slot_write(nxt, k);
-          round_load(k, c + 2, !(STV_DIAG & 1));
-        }
     }
-    __syncthreads();
+    // round l + 1 has landed once at most this round's PPW pieces are still in flight; the
+    // barrier then also says every wave is done reading `cur`, which round l + 3 will overwrite
+    wait_vmcnt<C::PPW>();
+    __builtin_amdgcn_s_barrier();
   };
 
-  // prologue: stage 0 -> LDS buffer 0, stage 1 in flight
+  // prologue: rounds 0 and 1 in flight, round 0 landed
+  char* const buf0 = ring;
+  char* const buf1 = ring + C::STAGE_BYTES;
+  char* const buf2 = ring + 2 * C::STAGE_BYTES;
 #pragma unroll
-  for (int k = 0; k < C::ITERS; ++k) round_load(k, 0, true);
-  char* const buf0 = smem + grp * (2 * C::STAGE_BYTES);
-  char* const buf1 = buf0 + C::STAGE_BYTES;
+  for (int k = 0; k < C::PPW; ++k) dma(k, 0, buf0);
 #pragma unroll
-  for (int k = 0; k < C::ITERS; ++k) {
-    slot_write(buf0, k);
-    round_load(k, 1, true);
-  }
-  __syncthreads();
+  for (int k = 0; k < C::PPW; ++k) dma(k, 1, buf1);
+  wait_vmcnt<C::PPW>();
+  __builtin_amdgcn_s_barrier();
   STV_STAMP(1);
 
   int c = 0;
-  for (; c + 1 < nrounds; c += 2) {
-    run_stage(buf0, buf1, c);
+  for (; c + 2 < nrounds; c += 3) {
+    run_stage(buf0, buf2, c);
     run_stage(buf1, buf0, c + 1);
+    run_stage(buf2, buf1, c + 2);
   }
-  if (c < nrounds) run_stage(buf0, buf1, c);
+  if (c < nrounds) run_stage(buf0, buf2, c);
+  if (c + 1 < nrounds) run_stage(buf1, buf0, c + 1);
+  // the zero-fill DMAs of the rounds past the end still target the ring: drain them before the
+  // C tile takes over the same LDS
+  wait_vmcnt<0>();
+  __syncthreads();
   STV_STAMP(2);
 
   // ---- epilogue: accumulators -> LDS C tile (fp32) -> 16-byte vector stores ----
@@ -388,6 +416,7 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
     __builtin_amdgcn_raw_buffer_store_b128(pack16<T>(val), rs_y, o_off[it], 0, 0);   // OOB lanes are dropped
   }
   STV_STAMP(4);
+#endif
 }
 
 // ---- generic direct fallback (any Cin/Cout; used for odd shapes in tests) ----

@@ -293,11 +293,14 @@ __global__ __launch_bounds__(256) void gram_partial_bf16_kernel(const bf16_t* __
       }
 }
 
-// FIN_E consecutive Gram elements per block, FIN_S ks-slices each, reduced through LDS in a
-// fixed order (deterministic).  loss_part gets one partial per block.
-constexpr int FIN_E = 32, FIN_S = 8;
-template <typename T>
-__global__ __launch_bounds__(256) void gram_finish_kernel(
+// FIN_E consecutive Gram elements (one 128-byte line of every slab) per block, FIN_S ks-slices
+// each, reduced through LDS in a fixed order (deterministic).  The slab walk is pure latency
+// (each element is one dword per slab), so a block keeps FIN_S x 8 slabs of loads in flight.
+// loss_part gets one partial per block.
+// FIN_S is 32 for long slab walks (small C: hundreds of slabs) and 8 for short ones.
+constexpr int FIN_E = 32, FIN_U = 8;
+template <typename T, int FIN_S>
+__global__ __launch_bounds__(FIN_E * FIN_S) void gram_finish_kernel(
     const float* __restrict__ partials, const float* __restrict__ target, float* __restrict__ gram_out,
     float* __restrict__ loss_part, T* __restrict__ sgrad, int C, int TS, int ksplit, float clamp_max,
     float norm, float k_grad, const float* __restrict__ coef_dev) {
@@ -306,39 +309,51 @@ __global__ __launch_bounds__(256) void gram_finish_kernel(
   const int slice = threadIdx.x / FIN_E;
   const int e = blockIdx.x * FIN_E + le;
   const int CC = C * C;
+  // Only tiles with tile(row) <= tile(col) were produced.  Elements of a lower tile have nothing
+  // to read: they are finished, as mirror images, by the thread that owns the upper-tile element,
+  // which reads the slabs row-wise (a transposed read of the slabs would touch one cache line per
+  // element).
+  const int i = e / C, j = e - i * C;
+  const bool lower = (i / TS) > (j / TS);
+  const bool mirror = (i / TS) < (j / TS);
   float s = 0.0f;
-  if (e < CC) {
-    const int i = e / C, j = e - i * C;
-    // only tiles with tile(row) <= tile(col) were produced; mirror the rest
-    const bool upper = (i / TS) <= (j / TS);
-    const size_t src = upper ? ((size_t)i * C + j) : ((size_t)j * C + i);
-    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+  if (e < CC && !lower) {
+    float acc[FIN_U];
+#pragma unroll
+    for (int u = 0; u < FIN_U; ++u) acc[u] = 0.0f;
     int ks = slice;
-    for (; ks + 3 * FIN_S < ksplit; ks += 4 * FIN_S) {
-      s0 += partials[(size_t)ks * CC + src];
-      s1 += partials[(size_t)(ks + FIN_S) * CC + src];
-      s2 += partials[(size_t)(ks + 2 * FIN_S) * CC + src];
-      s3 += partials[(size_t)(ks + 3 * FIN_S) * CC + src];
+    for (; ks + (FIN_U - 1) * FIN_S < ksplit; ks += FIN_U * FIN_S) {
+#pragma unroll
+      for (int u = 0; u < FIN_U; ++u) acc[u] += partials[(size_t)(ks + u * FIN_S) * CC + e];
     }
-    for (; ks < ksplit; ks += FIN_S) s0 += partials[(size_t)ks * CC + src];
-    s = (s0 + s1) + (s2 + s3);
+#pragma unroll
+    for (int u = 0; u < FIN_U; ++u)
+      if (ks + u * FIN_S < ksplit) acc[u] += partials[(size_t)(ks + u * FIN_S) * CC + e];
+    s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   }
   red[slice][le] = s;
   __syncthreads();
   if (slice == 0) {
     float d2 = 0.0f;
-    if (e < CC) {
+    if (e < CC && !lower) {
       float R = 0.0f;
 #pragma unroll
       for (int q = 0; q < FIN_S; ++q) R += red[q][le];
       const float Gv = fminf(R, clamp_max) / norm;
-      if (gram_out) gram_out[e] = Gv;
+      const float kk = (target && sgrad) ? k_grad * (coef_dev ? *coef_dev : 1.0f) : 0.0f;
+      const int em = j * C + i;                       // mirror image (strictly upper tiles only)
+      if (gram_out) {
+        gram_out[e] = Gv;
+        if (mirror) gram_out[em] = Gv;
+      }
       if (target) {
         const float d = Gv - target[e];
         d2 = d * d;
-        if (sgrad) {
-          const float kk = k_grad * (coef_dev ? *coef_dev : 1.0f);
-          elem_traits<T>::store(sgrad + e, (R <= clamp_max) ? kk * d : 0.0f);
+        if (sgrad) elem_traits<T>::store(sgrad + e, (R <= clamp_max) ? kk * d : 0.0f);
+        if (mirror) {
+          const float dm = Gv - target[em];
+          d2 += dm * dm;
+          if (sgrad) elem_traits<T>::store(sgrad + em, (R <= clamp_max) ? kk * dm : 0.0f);
         }
       }
     }
@@ -448,14 +463,18 @@ extern "C" int stv_gram_finish(const float* partials, const float* target, float
   const int blocks = stv_gram_loss_parts(C);
   // d(mean((G-T)^2))/dR = 2/C^2 * (G-T) / norm ; dF = (dR + dR^T) F = 2 dR F
   const float k_grad = coef * 4.0f / ((float)C * (float)C * norm);
-  if (dtype == STV_F32)
-    hipLaunchKernelGGL(gram_finish_kernel<float>, dim3(blocks), dim3(256), 0, st, partials, target,
-                       gram_out, loss_part, static_cast<float*>(sgrad), C, TS, ksplit, clamp_max,
-                       norm, k_grad, coef_dev);
-  else if (dtype == STV_BF16)
-    hipLaunchKernelGGL(gram_finish_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, partials, target,
-                       gram_out, loss_part, static_cast<bf16_t*>(sgrad), C, TS, ksplit, clamp_max,
-                       norm, k_grad, coef_dev);
+  const bool deep = ksplit >= 128;
+#define STV_FINISH(T, S)                                                                                     \
+  hipLaunchKernelGGL((gram_finish_kernel<T, S>), dim3(blocks), dim3(FIN_E * S), 0, st, partials, target,    \
+                     gram_out, loss_part, static_cast<T*>(sgrad), C, TS, ksplit, clamp_max, norm, k_grad, coef_dev)
+  if (dtype == STV_F32) {
+    if (deep) STV_FINISH(float, 32);
+    else STV_FINISH(float, 8);
+  } else if (dtype == STV_BF16) {
+    if (deep) STV_FINISH(bf16_t, 32);
+    else STV_FINISH(bf16_t, 8);
+  }
+#undef STV_FINISH
   else
     return STV_ERR_ARG;
   STV_CHECK_LAUNCH();

@@ -179,8 +179,11 @@ __global__ __launch_bounds__(256) void solve_kernel(CState* st, CWs w, int hist,
                                                     float tol_change) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int S = hist + 1;
-  float* sSY = reinterpret_cast<float*>(smem_raw);       // [m][m] logical order
-  float* sYY = sSY + (size_t)hist * hist;
+  // [m][m] tables in logical order; the odd row pitch makes both the column walk of the first
+  // loop and the row walks of the other two free of bank conflicts
+  const int P = hist | 1;
+  float* sSY = reinterpret_cast<float*>(smem_raw);
+  float* sYY = sSY + (size_t)hist * P;
   __shared__ int sh_skip, sh_pushed, sh_m, sh_head, sh_cslot, sh_mold;
   __shared__ float sh_newro, sh_H;
   __shared__ double sh_gs[MAX_S], sh_gy[MAX_S], sh_ro[MAX_S];
@@ -277,8 +280,8 @@ __global__ __launch_bounds__(256) void solve_kernel(CState* st, CWs w, int hist,
     for (int j = tid & 63; j < m; j += 64) {
       int col = head + j;
       if (col >= S) col -= S;
-      sSY[i * hist + j] = w.SY[row + col];
-      sYY[i * hist + j] = w.YY[row + col];
+      sSY[i * P + j] = w.SY[row + col];
+      sYY[i * P + j] = w.YY[row + col];
     }
   }
   __syncthreads();
@@ -303,33 +306,99 @@ __global__ __launch_bounds__(256) void solve_kernel(CState* st, CWs w, int hist,
   double cy0 = 0.0, cy1 = 0.0, cs0 = 0.0, cs1 = 0.0, al0 = 0.0, al1 = 0.0;
   double a0 = 0.0, a1 = 0.0;                // sum_{j > own} cy_j * SY[own][j], built incrementally
   double cg = -1.0;
-  for (int i = m - 1; i >= 0; --i) {
-    const bool hi = i >= 64;                 // wave-uniform: which owned slot holds index i
-    const double cand = (double)(float)((float)(cg * (hi ? gs1 : gs0) + (hi ? a1 : a0)) * (float)(hi ? ro1 : ro0));
-    const double al = bcast(cand, i & 63);   // fp32-rounded like torch's al[i]
-    if (i == j0) { al0 = al; cy0 = -al; }
-    if (i == j1) { al1 = al; cy1 = -al; }
-    if (j0 < i) a0 -= al * (double)sSY[j0 * hist + i];
-    if (j1 < i) a1 -= al * (double)sSY[j1 * hist + i];
+  // The three walks are serial in i; what each step needs from LDS does not depend on the chain,
+  // so it is fetched four steps ahead (CH values per owned index) while the previous four run.
+  constexpr int CH = 4;
+  {
+    float n0[CH], n1[CH];
+    auto fetch = [&](int ib) {                 // column entries SY[own][ib - k]
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        const int i = ib - k;
+        n0[k] = (i >= 0 && j0 < i) ? sSY[j0 * P + i] : 0.0f;
+        n1[k] = (i >= 0 && j1 < i) ? sSY[j1 * P + i] : 0.0f;
+      }
+    };
+    fetch(m - 1);
+    for (int ib = m - 1; ib >= 0; ib -= CH) {
+      float c0[CH], c1[CH];
+#pragma unroll
+      for (int k = 0; k < CH; ++k) { c0[k] = n0[k]; c1[k] = n1[k]; }
+      if (ib - CH >= 0) fetch(ib - CH);
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        const int i = ib - k;
+        if (i < 0) break;
+        const bool hi = i >= 64;               // wave-uniform: which owned slot holds index i
+        const double cand = (double)(float)((float)(cg * (hi ? gs1 : gs0) + (hi ? a1 : a0)) * (float)(hi ? ro1 : ro0));
+        const double al = bcast(cand, i & 63); // fp32-rounded like torch's al[i]
+        if (i == j0) { al0 = al; cy0 = -al; }
+        if (i == j1) { al1 = al; cy1 = -al; }
+        a0 -= al * (double)c0[k];              // entries outside j < i were fetched as zero
+        a1 -= al * (double)c1[k];
+      }
+    }
   }
   const double H = (double)sh_H;
   cg *= H; cy0 *= H; cy1 *= H;
   // b_own = cg*(g.y_own) + sum_j cy_j * YY[own][j]  (no recursion: cy is final)
   double b0 = cg * gy0, b1 = cg * gy1;
-  for (int j = 0; j < m; ++j) {
-    const double cyj = bcast(j >= 64 ? cy1 : cy0, j & 63);
-    if (j0 < m) b0 += cyj * (double)sYY[j0 * hist + j];
-    if (j1 < m) b1 += cyj * (double)sYY[j1 * hist + j];
+  {
+    float n0[CH], n1[CH];
+    auto fetch = [&](int jb) {
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        const int j = jb + k;
+        n0[k] = (j < m && j0 < m) ? sYY[j0 * P + j] : 0.0f;
+        n1[k] = (j < m && j1 < m) ? sYY[j1 * P + j] : 0.0f;
+      }
+    };
+    fetch(0);
+    for (int jb = 0; jb < m; jb += CH) {
+      float c0[CH], c1[CH];
+#pragma unroll
+      for (int k = 0; k < CH; ++k) { c0[k] = n0[k]; c1[k] = n1[k]; }
+      if (jb + CH < m) fetch(jb + CH);
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        const int j = jb + k;
+        if (j >= m) break;
+        const double cyj = bcast(j >= 64 ? cy1 : cy0, j & 63);
+        b0 += cyj * (double)c0[k];
+        b1 += cyj * (double)c1[k];
+      }
+    }
   }
-  for (int i = 0; i < m; ++i) {
-    const bool hi = i >= 64;
-    const double be = (double)(float)((float)(hi ? b1 : b0) * (float)(hi ? ro1 : ro0));
-    const double cand = (double)(float)((float)(hi ? al1 : al0) - (float)be);
-    const double csi = bcast(cand, i & 63);
-    if (i == j0) cs0 = csi;
-    if (i == j1) cs1 = csi;
-    if (j0 > i && j0 < m) b0 += csi * (double)sSY[i * hist + j0];   // (y_own . s_i) = SY[i][own]
-    if (j1 > i && j1 < m) b1 += csi * (double)sSY[i * hist + j1];
+  {
+    float n0[CH], n1[CH];
+    auto fetch = [&](int ib) {                 // row entries SY[ib + k][own] = (y_own . s_i)
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        const int i = ib + k;
+        n0[k] = (i < m && j0 > i && j0 < m) ? sSY[i * P + j0] : 0.0f;
+        n1[k] = (i < m && j1 > i && j1 < m) ? sSY[i * P + j1] : 0.0f;
+      }
+    };
+    fetch(0);
+    for (int ib = 0; ib < m; ib += CH) {
+      float c0[CH], c1[CH];
+#pragma unroll
+      for (int k = 0; k < CH; ++k) { c0[k] = n0[k]; c1[k] = n1[k]; }
+      if (ib + CH < m) fetch(ib + CH);
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        const int i = ib + k;
+        if (i >= m) break;
+        const bool hi = i >= 64;
+        const double be = (double)(float)((float)(hi ? b1 : b0) * (float)(hi ? ro1 : ro0));
+        const double cand = (double)(float)((float)(hi ? al1 : al0) - (float)be);
+        const double csi = bcast(cand, i & 63);
+        if (i == j0) cs0 = csi;
+        if (i == j1) cs1 = csi;
+        b0 += csi * (double)c0[k];
+        b1 += csi * (double)c1[k];
+      }
+    }
   }
   double gtd = 0.0;
   if (j0 < m) gtd += cy0 * sh_gy[j0] + cs0 * sh_gs[j0];
@@ -420,12 +489,12 @@ extern "C" int stv_lbfgsc_step(float* x, const float* grad, void* state, void* w
   const int ntiles = (int)(nn / tile);
   const int nparts = ntiles * 4;
   const CWs w = carve(workspace, n, history, nparts);
-  const size_t lds = 2 * (size_t)history * history * sizeof(float);
+  const size_t lds = 2 * (size_t)history * (size_t)(history | 1) * sizeof(float);
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize,
-                            2 * MAX_HIST * MAX_HIST * (int)sizeof(float)) != hipSuccess)
+                            2 * MAX_HIST * (MAX_HIST | 1) * (int)sizeof(float)) != hipSuccess)
       return STV_ERR_LAUNCH;
     attr = true;
   }

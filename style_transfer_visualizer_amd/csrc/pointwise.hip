@@ -226,23 +226,28 @@ __global__ __launch_bounds__(1024) void loss_combine_kernel(const float* __restr
                                                             const float* __restrict__ scale, int n_terms,
                                                             float style_w, float content_w,
                                                             float* __restrict__ losses, float* __restrict__ scores) {
-  __shared__ double red[16];
   __shared__ float term[64];
+  __shared__ int kind[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int k = 0; k < n_terms; ++k) {
-    const int off = table[3 * k], cnt = table[3 * k + 1];
-    double s = 0.0;
-    for (int i = tid; i < cnt; i += 1024) s += (double)parts[off + i];
-    s = wave_sum_d(s);
-    __syncthreads();
-    if (lane == 0) red[wave] = s;
-    __syncthreads();
-    if (tid == 0) {
-      double tot = 0.0;
-      for (int w = 0; w < 16; ++w) tot += red[w];
-      const float v = (float)(tot * (double)scale[k]);
+  // one wave per loss term (terms beyond 16 take further rounds): the terms reduce side by side
+  // instead of one after the other, each in a fixed order
+  for (int k = wave; k < n_terms; k += 16) {
+    const int off = table[3 * k], cnt = table[3 * k + 1], knd = table[3 * k + 2];
+    const float sc = scale[k];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int i = lane;
+    for (; i + 192 < cnt; i += 256) {
+      s0 += (double)parts[off + i];
+      s1 += (double)parts[off + i + 64];
+      s2 += (double)parts[off + i + 128];
+      s3 += (double)parts[off + i + 192];
+    }
+    for (; i < cnt; i += 64) s0 += (double)parts[off + i];
+    const double tot = wave_sum_d((s0 + s1) + (s2 + s3));
+    if (lane == 0) {
+      const float v = (float)(tot * (double)sc);
       losses[k] = v;
-      if (k < 64) term[k] = v;
+      if (k < 64) { term[k] = v; kind[k] = knd; }
     }
   }
   __syncthreads();
@@ -250,7 +255,7 @@ __global__ __launch_bounds__(1024) void loss_combine_kernel(const float* __restr
     float style = 0.0f, content = 0.0f;
     for (int k = 0; k < n_terms; ++k) {
       const float v = (k < 64) ? term[k] : losses[k];
-      if (table[3 * k + 2] == 0) style += v;
+      if (((k < 64) ? kind[k] : table[3 * k + 2]) == 0) style += v;   // every global round trip here is serial
       else content += v;
     }
     const float total = style_w * style + content_w * content;

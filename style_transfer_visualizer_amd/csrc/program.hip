@@ -17,10 +17,16 @@ namespace {
 
 int run_op(const stv_op_t& o, void* st) {
   switch (o.op) {
-    case STV_OP_CONV_FIRST_FWD:
+    case STV_OP_CONV_FIRST_FWD:   // p3 (optional): weights packed by stv_conv_first_pack
+      if (o.p3)
+        return stv_conv_first_fwd_packed(static_cast<const float*>(o.p0), static_cast<const float*>(o.p3),
+                                         static_cast<const float*>(o.p2), o.q0, o.H, o.W, o.cin, o.cout, o.dtype, st);
       return stv_conv_first_fwd(static_cast<const float*>(o.p0), static_cast<const float*>(o.p1),
                                 static_cast<const float*>(o.p2), o.q0, o.H, o.W, o.cin, o.cout, o.dtype, st);
-    case STV_OP_CONV_FIRST_DGRAD:
+    case STV_OP_CONV_FIRST_DGRAD:  // p2 (optional): packed weights
+      if (o.p2)
+        return stv_conv_first_dgrad_packed(o.p0, static_cast<const float*>(o.p2), static_cast<float*>(o.q0), o.H,
+                                           o.W, o.cin, o.cout, o.dtype, st);
       return stv_conv_first_dgrad(o.p0, static_cast<const float*>(o.p1), static_cast<float*>(o.q0), o.H,
                                   o.W, o.cin, o.cout, o.dtype, st);
     case STV_OP_CONV:

@@ -84,28 +84,49 @@ def from_nhwc(x: torch.Tensor) -> torch.Tensor:
 
 # ---- conv ---------------------------------------------------------------------
 
+def conv_first_pack(wf: torch.Tensor) -> torch.Tensor:
+    """Kernel-side packing of a frozen first-layer weight [9,Cout,Cin] (fp32), done once (stv_conv_first_pack)."""
+    _, cout, cin = wf.shape
+    lib = _lib.load()
+    packed = torch.empty(int(lib.stv_conv_first_packed_bytes(cin, cout)) // 4, device=wf.device, dtype=torch.float32)
+    _lib.check(lib.stv_conv_first_pack(_ptr(wf), _ptr(packed), cin, cout, _stream()), "stv_conv_first_pack")
+    return packed
+
+
 def conv_first_fwd(x_nchw: torch.Tensor, wf: torch.Tensor, bias: torch.Tensor | None,
-                   dtype: torch.dtype, out: torch.Tensor | None = None) -> torch.Tensor:
+                   dtype: torch.dtype, out: torch.Tensor | None = None, *,
+                   packed: torch.Tensor | None = None) -> torch.Tensor:
+    """``packed`` (from :func:`conv_first_pack`) skips the per-call weight repack."""
     _, cin, H, W = x_nchw.shape
     cout = wf.shape[1]
     if out is None:
         out = torch.empty(H, W, cout, device=x_nchw.device, dtype=dtype)
     lib = _lib.load()
-    _lib.check(lib.stv_conv_first_fwd(_ptr(x_nchw), _ptr(wf), _ptr(bias), _ptr(out), H, W, cin, cout,
-                                      dtype_code(dtype), _stream()), "stv_conv_first_fwd")
+    if packed is not None:
+        _lib.check(lib.stv_conv_first_fwd_packed(_ptr(x_nchw), _ptr(packed), _ptr(bias), _ptr(out), H, W, cin, cout,
+                                                 dtype_code(dtype), _stream()), "stv_conv_first_fwd_packed")
+    else:
+        _lib.check(lib.stv_conv_first_fwd(_ptr(x_nchw), _ptr(wf), _ptr(bias), _ptr(out), H, W, cin, cout,
+                                          dtype_code(dtype), _stream()), "stv_conv_first_fwd")
     return out
 
 
 def conv_first_dgrad(dy: torch.Tensor, wf: torch.Tensor, cin: int,
-                     out: torch.Tensor | None = None) -> torch.Tensor:
+                     out: torch.Tensor | None = None, *, packed: torch.Tensor | None = None) -> torch.Tensor:
     H, W, cout = dy.shape
     if out is None:
         out = torch.empty(1, cin, H, W, device=dy.device, dtype=torch.float32)
     lib = _lib.load()
-    _lib.check(lib.stv_conv_first_dgrad(_ptr(dy), _ptr(wf), _ptr(out), H, W, cin, cout,
-                                        dtype_code(dy.dtype), _stream()), "stv_conv_first_dgrad")
+    if packed is not None:
+        _lib.check(lib.stv_conv_first_dgrad_packed(_ptr(dy), _ptr(packed), _ptr(out), H, W, cin, cout,
+                                                   dtype_code(dy.dtype), _stream()), "stv_conv_first_dgrad_packed")
+    else:
+        _lib.check(lib.stv_conv_first_dgrad(_ptr(dy), _ptr(wf), _ptr(out), H, W, cin, cout,
+                                            dtype_code(dy.dtype), _stream()), "stv_conv_first_dgrad")
     return out
 
+
+# ---- conv ---------------------------------------------------------------------
 
 def conv_igemm(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None,
                ref: torch.Tensor | None = None, out: torch.Tensor | None = None,

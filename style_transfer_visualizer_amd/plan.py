@@ -136,6 +136,8 @@ class Schedule:
                         msg = "a ReLU in front of the first convolution is not supported"
                         raise RuntimeError(msg)
                     node = Node("conv_first", None, dst, layer=i, wf=ops.pack_weights_fwd(w), bias=bias, cin=cin)
+                    if w.is_cuda:
+                        node.wb = ops.conv_first_pack(node.wf)   # frozen weights: kernel-side packing, once
                 else:
                     wf = ops.pack_weights_fwd(w).to(self.dtype)
                     wb = ops.pack_weights_bwd(w).to(self.dtype) if self.with_grad else None
@@ -210,7 +212,7 @@ class Schedule:
         for nd in self.nodes:
             d = nd.dst
             if nd.kind == "conv_first":
-                out.append(self._op(op=OP_CONV_FIRST_FWD, p0=x, p1=nd.wf, p2=nd.bias, q0=d.act,
+                out.append(self._op(op=OP_CONV_FIRST_FWD, p0=x, p1=nd.wf, p2=nd.bias, p3=nd.wb, q0=d.act,
                                     H=d.H, W=d.W, cin=nd.cin, cout=d.C))
             elif nd.kind == "conv":
                 flags = ((RELU_IN if nd.relu_in else 0) | (RELU_OUT if d.relu_fused else 0)
@@ -275,7 +277,7 @@ class Schedule:
                 out.append(self._op(op=OP_RELU_BWD, p0=d.act, p1=d.grad, q0=d.grad, n=d.act.numel()))
             s = nd.src
             if nd.kind == "conv_first":
-                out.append(self._op(op=OP_CONV_FIRST_DGRAD, p0=d.grad, p1=nd.wf, q0=x_grad, H=d.H, W=d.W,
+                out.append(self._op(op=OP_CONV_FIRST_DGRAD, p0=d.grad, p1=nd.wf, p2=nd.wb, q0=x_grad, H=d.H, W=d.W,
                                     cin=nd.cin, cout=d.C))
                 continue
             mask_src = nd.relu_in or (s.relu_fused and not s.taps)
