@@ -51,7 +51,8 @@ def conv_flops(meta) -> float:
     return 2.0 * max(taps, 1) * cin * cout * H * W
 
 
-_CFG_NAMES = {0: "8, 128, 4, 2", 1: "8, 64, 4, 2", 2: "4, 128, 1, 4", 3: "4, 64, 2, 2"}
+_CFG_NAMES = {0: "8, 128, 4, 2", 1: "8, 64, 4, 2", 2: "4, 128, 1, 4", 3: "4, 64, 2, 2", 4: "4, 64, 2, 2"}
+_CFG_KS = {0: 1, 1: 1, 2: 1, 3: 1, 4: 2}
 
 
 def kernel_group(meta, OP, dtype_code: int = 1) -> str | None:
@@ -59,11 +60,11 @@ def kernel_group(meta, OP, dtype_code: int = 1) -> str | None:
     from style_transfer_visualizer_amd import _lib
     op, H, W, cin, cout, taps, _n = meta
     if op == OP["CONV"]:
-        cfg = _lib.load().stv_conv_config(H, W, cin, cout, dtype_code)
+        cfg = _lib.load().stv_conv_config(H, W, cin, cout, taps, dtype_code)
         elem = "unsigned short" if dtype_code == 1 else "float"
         if cfg < 0:
             return f"conv_direct_kernel<{elem}, {taps}>"
-        return f"conv_igemm_kernel<Cfg<{elem}, {_CFG_NAMES[cfg]}, {taps}>>"
+        return f"conv_igemm_kernel<Cfg<{elem}, {_CFG_NAMES[cfg]}, {taps}, {_CFG_KS[cfg]}>>"
     names = {OP["CONV_FIRST_FWD"]: "conv_first_fwd", OP["CONV_FIRST_DGRAD"]: "conv_first_dgrad",
              OP["POOL_FWD"]: "maxpool_fwd", OP["POOL_BWD"]: "maxpool_bwd", OP["GRAM_PARTIAL"]: "gram_partial",
              OP["GRAM_FINISH"]: "gram_finish", OP["CONTENT_LOSS"]: "content_loss",

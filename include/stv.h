@@ -88,13 +88,24 @@ int stv_conv_first_dgrad_packed(const void* dy, const float* packed, float* dx_n
  * With W_BLOCKED `w` is [taps][cin/CK][cout][CK] (CK = 16 bf16 / 8 fp32 channels,
  * cin % CK == 0): the 32-byte K slices a workgroup stages for its output channels
  * are then contiguous, so every weight load is a fully used cache line. */
+/* Optional, once per shape (e.g. when a schedule is built): time every tile
+ * configuration of stv_conv_igemm for this shape on scratch data and remember the
+ * fastest for later calls (process-wide table keyed by shape; the analytic choice
+ * is kept unless another tile is > 3 % faster).  Returns the configuration index
+ * (>= 0; the value stv_conv_config reports afterwards), -1 when the shape runs on
+ * the direct kernel (nothing to tune), or -(100 + STV_ERR_*) on failure.
+ * Synchronises `stream`.  STV_CONV_TUNE=0 in the environment disables measuring.
+ * Different tiles sum K in different orders: results agree to fp32 rounding, not
+ * bit for bit, across configurations. */
+int stv_conv_tune(int H, int W, int cin, int cout, int taps, int dtype, void* stream);
 int stv_conv_igemm(const void* x, const void* w, const float* bias, const void* ref,
                    void* y, int H, int W, int cin, int cout, int taps, int flags,
                    int dtype, void* stream);
 
 /* Which tile the dispatcher picks for a shape: -1 = scalar fallback (channel counts not a
- * multiple of the MFMA K-slice), else 0..3 = {8x128, 8x64, 4x128, 4x64} (rows x couts). */
-int stv_conv_config(int H, int W, int cin, int cout, int dtype);
+ * multiple of the MFMA K-slice), else 0..3 = {8x128, 8x64, 4x128, 4x64} (rows x couts) and
+ * 4 = 4x64 with K split over two wave groups. */
+int stv_conv_config(int H, int W, int cin, int cout, int taps, int dtype);
 
 /* MaxPool2d(2,2) forward / backward (first-max-wins like torch); backward
  * optionally applies the ReLU mask of the stored pre-pool activation. */

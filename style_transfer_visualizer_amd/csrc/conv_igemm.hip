@@ -29,6 +29,9 @@
 // weights, and the Gram backward product dF = F * S as a 1x1 conv.
 #include <stdlib.h>
 
+#include <mutex>
+#include <vector>
+
 #include <type_traits>
 
 #include "stv_common.h"
@@ -471,60 +474,157 @@ int launch_cfg(const ConvArgs& a, hipStream_t st) {
   return STV_OK;
 }
 
-// Tile choice: -1 = direct fallback, else index into {8x128, 8x64, 4x128, 4x64} (TH x BN).
-int choose_cfg(int H, int W, int cin, int cout, int elem_bytes) {
-  const int kVec = 16 / elem_bytes, CK = 32 / elem_bytes;
-  if ((cin % CK) || (cout % kVec)) return -1;
-  // Pick the tile that finishes first: waves of workgroups over 256 CUs x work per workgroup
-  // / relative efficiency of the tile (measured with tools/conv_sweep.py).
-  static const int th[4] = {8, 8, 4, 4}, bn[4] = {128, 64, 128, 64};
-  static const float eff_tab[2][4] = {{1.0f, 0.84f, 0.72f, 0.82f},    // cin >= 128
-                                      {1.0f, 0.84f, 0.72f, 0.91f}};   // short K: the 4-row tile holds up better
-  const float* eff = eff_tab[cin <= 64 ? 1 : 0];
+// ---- tile choice --------------------------------------------------------------------------------
+// Configurations: 0 = 8x128, 1 = 8x64, 2 = 4x128, 3 = 4x64 (TH x BN), 4 = 4x64 with K split over two
+// wave groups.  -1 = the shape is outside the matrix-core tiling (direct fallback).
+constexpr int kNumCfg = 5;
+const int kCfgTH[kNumCfg] = {8, 8, 4, 4, 4}, kCfgBN[kNumCfg] = {128, 64, 128, 64, 64};
+
+bool cfg_valid(int cfg, int cout) { return cfg >= 0 && cfg < kNumCfg && !(cout <= 64 && kCfgBN[cfg] == 128); }
+
+// Measured choices (stv_conv_tune), keyed by shape.
+struct TuneEntry { int H, W, cin, cout, taps, esize, cfg; };
+std::mutex g_tune_mu;
+std::vector<TuneEntry> g_tune;
+
+int tuned_cfg(int H, int W, int cin, int cout, int taps, int esize) {
+  std::lock_guard<std::mutex> lk(g_tune_mu);
+  for (const TuneEntry& e : g_tune)
+    if (e.H == H && e.W == W && e.cin == cin && e.cout == cout && e.taps == taps && e.esize == esize) return e.cfg;
+  return -1;
+}
+
+// Cost model for untuned shapes: waves of workgroups over 256 CUs x work per workgroup / relative
+// efficiency of the tile (measured with tools/conv_sweep.py on full-chip layers).
+int model_cfg(int H, int W, int cin, int cout) {
+  static const float eff[4] = {1.0f, 0.84f, 0.72f, 0.82f};
   int best = 0;
   float best_cost = 3.4e38f;
   for (int i = 0; i < 4; ++i) {
-    if (cout <= 64 && bn[i] == 128) continue;
-    const long blocks = (long)ceil_div(W, 32) * ceil_div(H, th[i]) * ceil_div(cout, bn[i]);
+    if (!cfg_valid(i, cout)) continue;
+    const long blocks = (long)ceil_div(W, 32) * ceil_div(H, kCfgTH[i]) * ceil_div(cout, kCfgBN[i]);
     const float waves = (float)((blocks + 255) / 256);   // eff is per CU, whatever the residency
-    const float cost = waves * (float)(th[i] * bn[i]) / eff[i];
+    const float cost = waves * (float)(kCfgTH[i] * kCfgBN[i]) / eff[i];
     if (cost < best_cost) { best_cost = cost; best = i; }
   }
+  // a grid that cannot give every CU a workgroup, on a deep K: split K inside the workgroup
+  const long blocks3 = (long)ceil_div(W, 32) * ceil_div(H, 4) * ceil_div(cout, 64);
+  if (best == 3 && blocks3 <= 256 && cin >= 256) best = 4;
+  return best;
+}
+
+int choose_cfg(int H, int W, int cin, int cout, int elem_bytes, int taps = 9) {
+  const int kVec = 16 / elem_bytes, CK = 32 / elem_bytes;
+  if ((cin % CK) || (cout % kVec)) return -1;
   if (const char* force = getenv("STV_CONV_CFG")) {   // tuning aid (tools/conv_sweep.py)
     const int f = atoi(force);
-    if (f >= 0 && f < 4 && !(cout <= 64 && bn[f] == 128)) best = f;
-    if (f == 4 && cout > 64) best = 4;   // experimental: 8x128 with waves as 2(M) x 4(N)
-    if (f == 5) best = 5;
+    if (cfg_valid(f, cout)) return f;
   }
-  return best;
+  const int t = tuned_cfg(H, W, cin, cout, taps, elem_bytes);
+  return t >= 0 ? t : model_cfg(H, W, cin, cout);
+}
+
+template <typename T, int TAPS>
+int launch_mfma(const ConvArgs& a, int cfg, hipStream_t st) {
+  switch (cfg) {
+    // the two 8-row tiles run 8 waves (two per SIMD: one wave's waits hide under the other's MFMAs)
+    case 0: return launch_cfg<Cfg<T, 8, 128, 4, 2, TAPS>>(a, st);   // 64 px x 64 couts per wave
+    case 1: return launch_cfg<Cfg<T, 8, 64, 4, 2, TAPS>>(a, st);    // 64 px x 32 couts per wave
+    case 2: return launch_cfg<Cfg<T, 4, 128, 1, 4, TAPS>>(a, st);
+    case 4: return launch_cfg<Cfg<T, 4, 64, 2, 2, TAPS, 2>>(a, st);   // small layers: K split over two wave groups
+    default: return launch_cfg<Cfg<T, 4, 64, 2, 2, TAPS>>(a, st);
+  }
 }
 
 template <typename T, int TAPS>
 int launch_typed(const ConvArgs& a, hipStream_t st) {
-  const bool mfma_ok = choose_cfg(a.H, a.W, a.cin, a.cout, (int)sizeof(T)) >= 0;
-  if (!mfma_ok) {
+  const int cfg = choose_cfg(a.H, a.W, a.cin, a.cout, (int)sizeof(T), TAPS);
+  if (cfg < 0) {
     const size_t total = (size_t)a.H * a.W * a.cout;
     hipLaunchKernelGGL((conv_direct_kernel<T, TAPS>), dim3((unsigned)((total + 255) / 256)),
                        dim3(256), 0, st, a);
     STV_CHECK_LAUNCH();
     return STV_OK;
   }
-  const int best = choose_cfg(a.H, a.W, a.cin, a.cout, (int)sizeof(T));
-  switch (best) {
-    // the two 8-row tiles run 8 waves (two per SIMD: one wave's waits hide under the other's MFMAs)
-    case 0: return launch_cfg<Cfg<T, 8, 128, 4, 2, TAPS>>(a, st);   // 64 px x 64 couts per wave
-    case 1: return launch_cfg<Cfg<T, 8, 64, 4, 2, TAPS>>(a, st);    // 64 px x 32 couts per wave
-    case 2: return launch_cfg<Cfg<T, 4, 128, 1, 4, TAPS>>(a, st);
-    case 4: return launch_cfg<Cfg<T, 8, 128, 2, 4, TAPS>>(a, st);
-    case 5: return launch_cfg<Cfg<T, 4, 64, 2, 2, TAPS, 2>>(a, st);   // small layers: K split over two wave groups
-    default: return launch_cfg<Cfg<T, 4, 64, 2, 2, TAPS>>(a, st);
+  return launch_mfma<T, TAPS>(a, cfg, st);
+}
+
+__global__ void tune_fill_kernel(uint32_t* p, size_t n_words, uint32_t seed) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_words) return;
+  uint32_t h = (uint32_t)i * 2654435761u + seed;
+  h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+  // two bf16 (or one fp32) of magnitude ~1e-2..1, random sign: realistic switching activity
+  p[i] = (h & 0x807F807Fu) | 0x3C003C00u;
+}
+
+template <typename T>
+int tune_typed(int H, int W, int cin, int cout, int taps, hipStream_t st) {
+  const size_t nx = (size_t)H * W * cin, nw = (size_t)taps * cout * cin, ny = (size_t)H * W * cout;
+  char* buf = nullptr;
+  const size_t bx = (nx * sizeof(T) + 255) / 256 * 256, bw = (nw * sizeof(T) + 255) / 256 * 256;
+  if (hipMalloc(reinterpret_cast<void**>(&buf), bx + bw + ny * sizeof(T)) != hipSuccess) return -(100 + STV_ERR_ALLOC);
+  const size_t words = (bx + bw) / 4;
+  hipLaunchKernelGGL(tune_fill_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st,
+                     reinterpret_cast<uint32_t*>(buf), words, 0x9E3779B9u);
+  ConvArgs a{buf, buf + bx, nullptr, nullptr, buf + bx + bw, H, W, cin, cout, STV_W_BLOCKED};
+  if (taps == 1) a.flags = 0;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  const int base = model_cfg(H, W, cin, cout);
+  int best = base;
+  float t_best = 3.4e38f, t_base = 3.4e38f;
+  int rc = STV_OK;
+  for (int cfg = 0; cfg < kNumCfg && rc == STV_OK; ++cfg) {
+    if (!cfg_valid(cfg, cout)) continue;
+    constexpr int kWarm = 2, kReps = 6;
+    for (int i = 0; i < kWarm && rc == STV_OK; ++i)
+      rc = taps == 9 ? launch_mfma<T, 9>(a, cfg, st) : launch_mfma<T, 1>(a, cfg, st);
+    (void)hipEventRecord(e0, st);
+    for (int i = 0; i < kReps && rc == STV_OK; ++i)
+      rc = taps == 9 ? launch_mfma<T, 9>(a, cfg, st) : launch_mfma<T, 1>(a, cfg, st);
+    (void)hipEventRecord(e1, st);
+    if (hipEventSynchronize(e1) != hipSuccess) rc = STV_ERR_LAUNCH;
+    float ms = 0.0f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (cfg == base) t_base = ms;
+    if (ms < t_best) { t_best = ms; best = cfg; }
   }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(buf);
+  if (rc != STV_OK) return -(100 + rc);
+  // keep the model's choice unless something else is clearly (3 %) faster: fewer flips run to run
+  if (best != base && t_best > 0.97f * t_base) best = base;
+  std::lock_guard<std::mutex> lk(g_tune_mu);
+  for (TuneEntry& e : g_tune)
+    if (e.H == H && e.W == W && e.cin == cin && e.cout == cout && e.taps == taps && e.esize == (int)sizeof(T)) {
+      e.cfg = best;
+      return best;
+    }
+  g_tune.push_back(TuneEntry{H, W, cin, cout, taps, (int)sizeof(T), best});
+  return best;
 }
 
 }  // namespace
 
-extern "C" int stv_conv_config(int H, int W, int cin, int cout, int dtype) {
-  return choose_cfg(H, W, cin, cout, dtype == STV_BF16 ? 2 : 4);
+extern "C" int stv_conv_config(int H, int W, int cin, int cout, int taps, int dtype) {
+  return choose_cfg(H, W, cin, cout, dtype == STV_BF16 ? 2 : 4, taps);
+}
+
+extern "C" int stv_conv_tune(int H, int W, int cin, int cout, int taps, int dtype, void* stream) {
+  if (H <= 0 || W <= 0 || cin <= 0 || cout <= 0 || (taps != 9 && taps != 1)) return -(100 + STV_ERR_ARG);
+  if (dtype != STV_F32 && dtype != STV_BF16) return -(100 + STV_ERR_ARG);
+  if ((size_t)H * W * (size_t)(cin > cout ? cin : cout) >= (size_t)1 << 31) return -(100 + STV_ERR_ARG);
+  const int esize = dtype == STV_BF16 ? 2 : 4;
+  if ((cin % (32 / esize)) || (cout % (16 / esize))) return -1;          // direct-kernel shape: nothing to tune
+  if (const char* off = getenv("STV_CONV_TUNE"))
+    if (atoi(off) == 0) return choose_cfg(H, W, cin, cout, esize, taps);
+  const int known = tuned_cfg(H, W, cin, cout, taps, esize);
+  if (known >= 0) return known;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  return dtype == STV_BF16 ? tune_typed<bf16_t>(H, W, cin, cout, taps, st) : tune_typed<float>(H, W, cin, cout, taps, st);
 }
 
 extern "C" int stv_conv_igemm(const void* x, const void* w, const float* bias, const void* ref,
@@ -534,7 +634,7 @@ extern "C" int stv_conv_igemm(const void* x, const void* w, const float* bias, c
   if ((flags & STV_MASK) && !ref) return STV_ERR_ARG;
   if (taps != 9 && taps != 1) return STV_ERR_ARG;
   // the direct fallback (shapes the matrix-core tiling does not cover) reads plain weights only
-  if ((flags & STV_W_BLOCKED) && choose_cfg(H, W, cin, cout, dtype == STV_F32 ? 4 : 2) < 0) return STV_ERR_ARG;
+  if ((flags & STV_W_BLOCKED) && choose_cfg(H, W, cin, cout, dtype == STV_F32 ? 4 : 2, taps) < 0) return STV_ERR_ARG;
   if ((size_t)H * W * (size_t)(cin > cout ? cin : cout) >= (size_t)1 << 31) return STV_ERR_ARG;
   ConvArgs a{x, w, bias, ref, y, H, W, cin, cout, flags};
   hipStream_t st = static_cast<hipStream_t>(stream);

@@ -70,7 +70,15 @@ def block_weights(w: torch.Tensor) -> torch.Tensor:
 
 def conv_uses_mfma(H: int, W: int, cin: int, cout: int, dtype: torch.dtype) -> bool:
     """True when stv_conv_igemm runs this shape on the matrix cores (else: direct kernel, plain weights)."""
-    return int(_lib.load().stv_conv_config(H, W, cin, cout, dtype_code(dtype))) >= 0
+    return int(_lib.load().stv_conv_config(H, W, cin, cout, 9, dtype_code(dtype))) >= 0
+
+
+def conv_tune(H: int, W: int, cin: int, cout: int, taps: int, dtype: torch.dtype) -> int:
+    """Measure the tile configurations for one conv shape once (stv_conv_tune); returns the choice (-1: direct kernel)."""
+    r = int(_lib.load().stv_conv_tune(H, W, cin, cout, taps, dtype_code(dtype), _stream()))
+    if r < -1:
+        _lib.check(-r - 100, "stv_conv_tune")
+    return r
 
 
 def to_nhwc(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:

@@ -147,6 +147,10 @@ class Schedule:
                         wf = ops.block_weights(wf)
                     if blocked and wb is not None and ops.conv_uses_mfma(H, W, cout, cin, self.dtype):
                         wb = ops.block_weights(wb)
+                    if w.is_cuda:      # measure the tile configurations of this layer's shapes once
+                        ops.conv_tune(H, W, cin, cout, 9, self.dtype)
+                        if self.with_grad:
+                            ops.conv_tune(H, W, cout, cin, 9, self.dtype)
                     node = Node("conv", cur, dst, relu_in=pending_relu, layer=i, wf=wf, wb=wb, bias=bias, cin=cin)
                 pending_relu = False
                 if i + 1 <= last and kinds[i + 1] == "relu" and i not in tapped:
@@ -262,6 +266,8 @@ class Schedule:
             d = nd.dst
             for tap in d.taps:
                 if tap.kind == "style":
+                    if d.act.is_cuda:
+                        ops.conv_tune(d.H, d.W, d.C, d.C, 1, self.dtype)     # cached per shape
                     out.append(self._op(op=OP_CONV, p0=d.act, p1=tap.sgrad, q0=d.grad, H=d.H, W=d.W,
                                         cin=d.C, cout=d.C, taps=1, flags=acc_flag(d)))
                 else:

@@ -121,12 +121,12 @@ def test_conv_igemm_forward(dtype, case, flags, blocked):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("case", [(128, 128, 21, 70), (64, 64, 9, 33), (48, 136, 12, 40), (512, 128, 8, 8)])
 def test_conv_igemm_every_tile_config(dtype, cfg, case, monkeypatch):
     """Each tile shape / wave layout / K split (forced with STV_CONV_CFG) on full, ragged and odd-K shapes."""
     cin, cout, H, W = case
-    if cout <= 64 and cfg in (0, 2, 4):
+    if cout <= 64 and cfg in (0, 2):
         pytest.skip("128-channel tiles need more than 64 output channels")
     monkeypatch.setenv("STV_CONV_CFG", str(cfg))
     x = rnd((1, cin, H, W), 41)
