@@ -104,7 +104,7 @@ int stv_conv_igemm(const void* x, const void* w, const float* bias, const void* 
 
 /* Which tile the dispatcher picks for a shape: -1 = scalar fallback (channel counts not a
  * multiple of the MFMA K-slice), else 0..3 = {8x128, 8x64, 4x128, 4x64} (rows x couts) and
- * 4 = 4x64 with K split over two wave groups. */
+ * 4 = 4x64 with K split over two wave groups, 5 = 8x64 with a two-deep LDS ring. */
 int stv_conv_config(int H, int W, int cin, int cout, int taps, int dtype);
 
 /* MaxPool2d(2,2) forward / backward (first-max-wins like torch); backward

@@ -48,6 +48,14 @@ def run_layer(layer: Layer, x: torch.Tensor) -> torch.Tensor:
         return F.relu(x)  # out-of-place, core_model.py:134-135
     if kind == "pool":
         return F.max_pool2d(x, kernel_size=2, stride=2)
+    # Decision-locked variants (tests only): the ReLU on/off pattern and the max-pool argmax are
+    # given instead of derived from x, so that two evaluations that disagree on a near-tie can be
+    # compared on the same piecewise-linear branch of the network.
+    if kind == "relu_mask":
+        return x * layer[1].to(x.dtype)
+    if kind == "pool_idx":
+        n, c, h, w = x.shape
+        return x.flatten(2).gather(2, layer[1].flatten(2)).reshape(n, c, h // 2, w // 2)
     msg = f"unknown layer kind {kind}"
     raise ValueError(msg)
 

@@ -56,7 +56,7 @@ __device__ unsigned long long g_stv_stamps[8 * 16384];
 
 namespace {
 
-template <typename T, int TH_, int BN_, int WM_, int WN_, int TAPS_, int KS_ = 1>
+template <typename T, int TH_, int BN_, int WM_, int WN_, int TAPS_, int KS_ = 1, int NBUF_ = 3>
 struct Cfg {
   using Elem = T;
   static constexpr int TH = TH_, BN = BN_, WM = WM_, WN = WN_, TAPS = TAPS_;
@@ -88,7 +88,10 @@ struct Cfg {
   static constexpr int IN_BYTES = IN_PIECES * 1024;
   static constexpr int SPARE_OFF = PIECES * 1024;
   static constexpr int STAGE_BYTES = SPARE_OFF + 1024;
-  static constexpr int NBUF = 3;                     // LDS ring: the DMA runs two stages ahead
+  // LDS ring: 3 = the DMA runs two stages ahead (one workgroup per CU has to hide its own
+  // latencies); 2 = one stage ahead at 2/3 of the LDS, so that two workgroups share a CU and
+  // cover each other's prologue, epilogue and waits
+  static constexpr int NBUF = NBUF_;
   static constexpr int BM = TH * TW;
   static constexpr int CS = BN + 4;                  // C-tile pitch in floats
   static constexpr int C_BYTES = BM * CS * 4;
@@ -96,6 +99,7 @@ struct Cfg {
   static constexpr int LDS_BYTES = (RING_BYTES > C_BYTES) ? RING_BYTES : C_BYTES;
   static_assert(NWAVES * KS == 4 || NWAVES * KS == 8, "4 or 8 waves per workgroup");
   static_assert(KS == 1 || KS == 2, "K split");
+  static_assert(NBUF == 2 || NBUF == 3, "ring depth");
   static_assert(TH % WM == 0 && BN % (WN * 32) == 0, "tile split");
   static_assert(BN % 16 == 0, "swizzle period");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
       // the next steps' LDS reads and this step's DMAs are issued first, then the MFMAs back to back
 #pragma unroll
       for (int k = step * PER; k < (step + 1) * PER; ++k)
-        if (k < C::PPW) dma(k, l + 2, fill);
+        if (k < C::PPW) dma(k, l + C::NBUF - 1, fill);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int mt = 0; mt < C::MT; ++mt)
@@ -306,32 +310,42 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
         for (int nt = 0; nt < C::NT; ++nt) mma<T>(af[dx & 1][mt + dy], bf[step % (PFB + 1)][nt], acc[mt][nt]);
       __builtin_amdgcn_sched_barrier(0);
     }
-    // round l + 1 has landed once at most this round's PPW pieces are still in flight; the
-    // barrier then also says every wave is done reading `cur`, which round l + 3 will overwrite
-    wait_vmcnt<C::PPW>();
+    // round l + 1 has landed once at most the pieces of the rounds after it are still in flight;
+    // the barrier then also says every wave is done reading `cur`, which the next fill overwrites
+    wait_vmcnt<(C::NBUF - 2) * C::PPW>();
     __builtin_amdgcn_s_barrier();
   };
 
-  // prologue: rounds 0 and 1 in flight, round 0 landed
+  // prologue: rounds 0 .. NBUF-2 in flight, round 0 landed
   char* const buf0 = ring;
   char* const buf1 = ring + C::STAGE_BYTES;
-  char* const buf2 = ring + 2 * C::STAGE_BYTES;
+  char* const buf2 = ring + (C::NBUF - 1) * C::STAGE_BYTES;       // only used when NBUF == 3
 #pragma unroll
   for (int k = 0; k < C::PPW; ++k) dma(k, 0, buf0);
+  if (C::NBUF == 3) {
 #pragma unroll
-  for (int k = 0; k < C::PPW; ++k) dma(k, 1, buf1);
-  wait_vmcnt<C::PPW>();
+    for (int k = 0; k < C::PPW; ++k) dma(k, 1, buf1);
+  }
+  wait_vmcnt<(C::NBUF - 2) * C::PPW>();
   __builtin_amdgcn_s_barrier();
   STV_STAMP(1);
 
   int c = 0;
-  for (; c + 2 < nrounds; c += 3) {
-    run_stage(buf0, buf2, c);
-    run_stage(buf1, buf0, c + 1);
-    run_stage(buf2, buf1, c + 2);
+  if (C::NBUF == 3) {
+    for (; c + 2 < nrounds; c += 3) {
+      run_stage(buf0, buf2, c);
+      run_stage(buf1, buf0, c + 1);
+      run_stage(buf2, buf1, c + 2);
+    }
+    if (c < nrounds) run_stage(buf0, buf2, c);
+    if (c + 1 < nrounds) run_stage(buf1, buf0, c + 1);
+  } else {
+    for (; c + 1 < nrounds; c += 2) {
+      run_stage(buf0, buf1, c);
+      run_stage(buf1, buf0, c + 1);
+    }
+    if (c < nrounds) run_stage(buf0, buf1, c);
   }
-  if (c < nrounds) run_stage(buf0, buf2, c);
-  if (c + 1 < nrounds) run_stage(buf1, buf0, c + 1);
   // the zero-fill DMAs of the rounds past the end still target the ring: drain them before the
   // C tile takes over the same LDS
   wait_vmcnt<0>();
@@ -476,9 +490,9 @@ int launch_cfg(const ConvArgs& a, hipStream_t st) {
 
 // ---- tile choice --------------------------------------------------------------------------------
 // Configurations: 0 = 8x128, 1 = 8x64, 2 = 4x128, 3 = 4x64 (TH x BN), 4 = 4x64 with K split over two
-// wave groups.  -1 = the shape is outside the matrix-core tiling (direct fallback).
-constexpr int kNumCfg = 5;
-const int kCfgTH[kNumCfg] = {8, 8, 4, 4, 4}, kCfgBN[kNumCfg] = {128, 64, 128, 64, 64};
+// wave groups, 5 = 8x64 on a two-deep LDS ring (two workgroups per CU).  -1 = the shape is outside the matrix-core tiling (direct fallback).
+constexpr int kNumCfg = 6;
+const int kCfgTH[kNumCfg] = {8, 8, 4, 4, 4, 8}, kCfgBN[kNumCfg] = {128, 64, 128, 64, 64, 64};
 
 bool cfg_valid(int cfg, int cout) { return cfg >= 0 && cfg < kNumCfg && !(cout <= 64 && kCfgBN[cfg] == 128); }
 
@@ -532,6 +546,7 @@ int launch_mfma(const ConvArgs& a, int cfg, hipStream_t st) {
     case 1: return launch_cfg<Cfg<T, 8, 64, 4, 2, TAPS>>(a, st);    // 64 px x 32 couts per wave
     case 2: return launch_cfg<Cfg<T, 4, 128, 1, 4, TAPS>>(a, st);
     case 4: return launch_cfg<Cfg<T, 4, 64, 2, 2, TAPS, 2>>(a, st);   // small layers: K split over two wave groups
+    case 5: return launch_cfg<Cfg<T, 8, 64, 4, 2, TAPS, 1, 2>>(a, st);
     default: return launch_cfg<Cfg<T, 4, 64, 2, 2, TAPS>>(a, st);
   }
 }

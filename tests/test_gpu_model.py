@@ -134,7 +134,7 @@ def test_trajectory_matches_reference(golden_case: GoldenCase, monkeypatch):
             opt2 = optimizers.HipAdam([x2], lr=m["adam_lr"])
         out2, _, _ = optimization.OptimizationRunner(model2, x2, cfg, optimizer=opt2, progress_bar=_Bar()).run()
         self_dev = float((out2 - out).abs().max() / out.abs().max())
-        ptol = max(ptol, 4.0 * self_dev)
+        ptol = max(ptol, 10.0 * self_dev)      # one probe is a noisy estimate of the spread: leave a decade
     ltol = max(1e-3, 10 * ptol)
     np.testing.assert_allclose(history["total_loss"][:upto], ref_total[:upto], rtol=ltol)
     # the two terms: relative, with an absolute floor of 1e-6 of the total for a weighted term that
@@ -184,6 +184,26 @@ def _decision_flips(model, oracle64, x64):
     return flips, worst
 
 
+def _locked_oracle(model, oracle64):
+    """Copy of the fp64 oracle whose ReLU masks and max-pool argmaxes are the HIP path's."""
+    import copy
+    import torch.nn.functional as F
+    from style_transfer_visualizer_amd import ops
+    eng = next(iter(model._engines.values()))
+    prog = list(oracle64.program)
+    for nd in eng.sched.nodes:
+        if nd.kind in ("conv", "conv_first") and nd.layer + 1 < len(prog) and prog[nd.layer + 1][0] == "relu":
+            prog[nd.layer + 1] = ("relu_mask", ops.from_nhwc(nd.dst.act).cpu() > 0)    # fused or not: act > 0 <=> z > 0
+        elif nd.kind == "relu":
+            prog[nd.layer] = ("relu_mask", ops.from_nhwc(nd.dst.act).cpu() > 0)
+        elif nd.kind == "pool":
+            _, idx = F.max_pool2d(ops.from_nhwc(nd.src.act).cpu().double(), 2, 2, return_indices=True)
+            prog[nd.layer] = ("pool_idx", idx)
+    locked = copy.copy(oracle64)
+    locked.program = prog
+    return locked
+
+
 @pytest.mark.parametrize("compact", [False, True])
 @pytest.mark.parametrize("name", ["mini_content_lbfgs", "mini_random_lbfgs_nonorm", "vgg19_content_lbfgs"])
 def test_every_step_matches_oracle_at_same_image(name, compact, monkeypatch):
@@ -231,8 +251,13 @@ def test_every_step_matches_oracle_at_same_image(name, compact, monkeypatch):
             # every differing ReLU / max-pool decision must be a genuine near-tie of the fp64 values
             assert worst_gap < 1e-4, f"step {step + 1}: decision differs at a gap of {worst_gap:.2e} of the layer scale"
             assert flips <= 8
-            err = (g.double() - g64).abs() / g64.abs().max()
-            assert float(err.median()) < 2e-5, f"step {step + 1}"
+            # on the branch of the network the HIP path actually took (its ReLU masks and pool
+            # argmaxes imposed on the fp64 oracle) the gradient must again be fp32-accurate
+            _, _, _, g64_locked = ocm.loss_and_grad(_locked_oracle(model, oracle64), xc.double(), m["style_w"],
+                                                    m["content_w"])
+            err_locked = float((g.double() - g64_locked).norm() / g64_locked.norm())
+            assert err_locked <= max(3 * err_cpu, 2e-5), \
+                f"step {step + 1}: HIP {err_locked:.2e} on its own branch vs CPU-fp32 {err_cpu:.2e}"
         twin.step(lambda: (t.cpu(), g))
         ops.lbfgs_step(x.detach(), x.grad, state, work, 100, min(step, 100), 1.0, compact=compact)
         drift = float((x.detach().cpu() - x_twin).abs().max() / x_twin.abs().max())
