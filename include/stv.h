@@ -148,7 +148,8 @@ int stv_content_grad(const void* F, const void* target, void* dF, size_t n, floa
  *      loss = style_w*style + content_w*content (optimization.py:298-312).
  *  table: int32 [n_terms][3] = {offset into parts, count, kind(0 style,1 content)}
  *  scale: fp32 [n_terms] (1/C^2 for style, 1/n for content)
- *  losses: fp32 [n_terms]; scores: fp32 [4] = {style, content, total, finite_flag} */
+ *  losses: fp32 [n_terms]; scores: fp32 [4] = {style, content, total, finite_flag}
+ *  n_terms <= 64 (STV_ERR_ARG beyond). */
 int stv_loss_combine(const float* parts, const int32_t* table, const float* scale,
                      int n_terms, float style_w, float content_w, float* losses,
                      float* scores, void* stream);

@@ -6,6 +6,10 @@
 // activation.  A wave covers 64/LP consecutive pixels with LP lanes per pixel,
 // each lane owning one 16-byte channel vector, so every activation access is a
 // fully coalesced 1 KiB wave transaction.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "stv_common.h"
 
 namespace {
@@ -217,6 +221,140 @@ __global__ __launch_bounds__(256) void conv_first_dgrad_c64(const T* __restrict_
   }
 }
 
+// ---- forward on the matrix cores (bf16 activations) ------------------------------------------------
+// K = 27 padded to 32 is two v_mfma_f32_32x32x16_bf16 steps; what keeps it fp32-faithful is a
+// two-term bf16 split of BOTH operands (v = hi + lo, each bf16): x.w ~ hi.hi + hi.lo + lo.hi, error
+// ~2^-16 relative - far below the bf16 rounding of the stored output.  6 MFMAs per 32 px x 32
+// couts instead of 27 x 32 VALU FMAs per lane: the kernel is left with the 64-channel NHWC write.
+// k = tap * 3 + c (27..31 zero).  One workgroup = 8 rows x 32 px, wave w owns rows 2w, 2w+1.
+constexpr int MF_TH = 8, MF_TW = 32, MF_IW = MF_TW + 2 + 2;   // LDS row pitch 36 floats
+constexpr int MF_PLANE = (MF_TH + 2) * MF_IW;
+constexpr int MF_FRAG_WORDS = 2 * 2 * 2 * 64 * 4;           // [hi|lo][kstep][nt][lane] x 4 dwords
+
+__global__ void pack_first_fragments(const float* __restrict__ wf, uint32_t* __restrict__ frag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;        // one bf16 pair per thread
+  if (i >= MF_FRAG_WORDS) return;
+  const int q = i & 3, lane = (i >> 2) & 63, nt = (i >> 8) & 1, ks = (i >> 9) & 1, part = i >> 10;
+  const int r = lane & 31, h = lane >> 5;
+  uint32_t out = 0;
+  for (int e2 = 0; e2 < 2; ++e2) {
+    const int k = ks * 16 + 8 * h + 2 * q + e2;
+    float v = 0.0f;
+    if (k < 27) v = wf[((k / 3) * 64 + nt * 32 + r) * 3 + (k % 3)];
+    const bf16_t hi = f32_to_bf16(v);
+    const bf16_t lo = f32_to_bf16(v - bf16_to_f32(hi));
+    out |= (uint32_t)(part ? lo : hi) << (16 * e2);
+  }
+  frag[i] = out;
+}
+
+__global__ __launch_bounds__(256) void conv_first_fwd_mfma(const float* __restrict__ x,
+                                                           const uint32_t* __restrict__ frag,
+                                                           const float* __restrict__ bias,
+                                                           bf16_t* __restrict__ y, int H, int W) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int CS = 64 + 4;                                 // C-tile pitch (floats)
+  __shared__ __attribute__((aligned(16))) float xs[3 * MF_PLANE + 4];   // [c][row][col], last word = 0
+  __shared__ __attribute__((aligned(16))) float cs[MF_TH * MF_TW * CS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int tiles_x = (W + MF_TW - 1) / MF_TW;
+  const int x0 = (blockIdx.x % tiles_x) * MF_TW, y0 = (blockIdx.x / tiles_x) * MF_TH;
+  for (int i = tid; i < 3 * MF_PLANE; i += 256) {
+    const int c = i / MF_PLANE, rem = i - c * MF_PLANE, py = rem / MF_IW, px = rem - py * MF_IW;
+    const int gy = y0 + py - 1, gx = x0 + px - 1;
+    xs[i] = (px < MF_TW + 2 && gy >= 0 && gy < H && gx >= 0 && gx < W) ? x[((size_t)c * H + gy) * W + gx] : 0.0f;
+  }
+  if (tid < 4) xs[3 * MF_PLANE + tid] = 0.0f;
+  // weight fragments: [hi|lo][kstep][nt] for this lane, 16 bytes each
+  bf16x8v bw[2][2][2];
+#pragma unroll
+  for (int part = 0; part < 2; ++part)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const u32x4 t = *reinterpret_cast<const u32x4*>(frag + ((((part * 2 + ks) * 2 + nt) * 64 + lane) << 2));
+        bw[part][ks][nt] = __builtin_bit_cast(bf16x8v, t);
+      }
+  // LDS word offsets of this lane's 16 K entries relative to (row, r): c * plane + dy * pitch + dx
+  int koff[2][8];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = ks * 16 + 8 * h + e;
+      const int tap = k / 3, c = k - tap * 3;
+      koff[ks][e] = (k < 27) ? c * MF_PLANE + (tap / 3) * MF_IW + (tap % 3) : -1;
+    }
+  __syncthreads();
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.0f;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int base = (wave * 2 + mt) * MF_IW + r;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint32_t hi4[4], lo4[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v[2];
+#pragma unroll
+        for (int e2 = 0; e2 < 2; ++e2) {
+          const int o = koff[ks][2 * q + e2];
+          v[e2] = xs[o >= 0 ? base + o : 3 * MF_PLANE];
+        }
+        const bf16_t h0 = f32_to_bf16(v[0]), h1 = f32_to_bf16(v[1]);
+        hi4[q] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+        lo4[q] = pack_bf16x2(v[0] - bf16_to_f32(h0), v[1] - bf16_to_f32(h1));
+      }
+      const bf16x8v a_hi = __builtin_bit_cast(bf16x8v, (u32x4){hi4[0], hi4[1], hi4[2], hi4[3]});
+      const bf16x8v a_lo = __builtin_bit_cast(bf16x8v, (u32x4){lo4[0], lo4[1], lo4[2], lo4[3]});
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, bw[0][ks][nt], acc[mt][nt], 0, 0, 0);
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bw[1][ks][nt], acc[mt][nt], 0, 0, 0);
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bw[0][ks][nt], acc[mt][nt], 0, 0, 0);
+      }
+    }
+  }
+  // accumulators -> C tile (each wave its own 64 pixel rows), then 16-byte NHWC stores
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = (wave * 2 + mt) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        cs[row * CS + nt * 32 + r] = acc[mt][nt][i];
+      }
+  __syncthreads();
+  const int cv = tid & 7;                                   // 8 vectors of 8 channels per pixel
+  float bv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bv[e] = bias ? bias[cv * 8 + e] : 0.0f;
+#pragma unroll
+  for (int it = 0; it < MF_TH * MF_TW * 8 / 256; ++it) {
+    const int pix = (it * 256 + tid) >> 3;
+    const int gy = y0 + (pix >> 5), gx = x0 + (pix & 31);
+    if (gy >= H || gx >= W) continue;
+    float val[8];
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(cs + pix * CS + cv * 8 + qq * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) val[qq * 4 + e] = t[e] + bv[qq * 4 + e];
+    }
+    *reinterpret_cast<u32x4*>(y + ((size_t)gy * W + gx) * 64 + cv * 8) = pack16<bf16_t>(val);
+  }
+#endif
+}
+
 // repack [9][64][3] -> [9][3][64] (fwd) or flipped taps (dgrad); tiny, run per call on the stream
 __global__ void repack_first_weights(const float* __restrict__ wf, float* __restrict__ wt, int flip) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -285,6 +423,13 @@ float* first_scratch() {
 template <typename T>
 int fwd_typed(const float* x, const float* wf, const float* packed, const float* bias, void* y, int H, int W,
               int cin, int cout, hipStream_t st) {
+  if (cin == 3 && cout == 64 && packed && std::is_same<T, bf16_t>::value && !getenv("STV_FIRST_VALU")) {
+    const int tiles = ceil_div(W, MF_TW) * ceil_div(H, MF_TH);
+    hipLaunchKernelGGL(conv_first_fwd_mfma, dim3(tiles), dim3(256), 0, st, x,
+                       reinterpret_cast<const uint32_t*>(packed + 2 * 1728), bias, static_cast<bf16_t*>(y), H, W);
+    STV_CHECK_LAUNCH();
+    return STV_OK;
+  }
   if (cin == 3 && cout == 64) {
     const float* wt = packed;
     if (!wt) {
@@ -355,7 +500,8 @@ int dgrad_typed(const void* dy, const float* wf, const float* packed, float* dx,
 }  // namespace
 
 extern "C" size_t stv_conv_first_packed_bytes(int cin, int cout) {
-  return (size_t)2 * 9 * (size_t)(cin > 0 ? cin : 0) * (size_t)(cout > 0 ? cout : 0) * sizeof(float);
+  const size_t plain = (size_t)2 * 9 * (size_t)(cin > 0 ? cin : 0) * (size_t)(cout > 0 ? cout : 0) * sizeof(float);
+  return (cin == 3 && cout == 64) ? plain + (size_t)MF_FRAG_WORDS * 4 : plain;   // + matrix-core weight fragments
 }
 
 extern "C" int stv_conv_first_pack(const float* wf, float* packed, int cin, int cout, void* stream) {
@@ -364,6 +510,8 @@ extern "C" int stv_conv_first_pack(const float* wf, float* packed, int cin, int 
   if (cin == 3 && cout == 64) {
     hipLaunchKernelGGL(repack_first_weights, dim3(7), dim3(256), 0, st, wf, packed, 0);
     hipLaunchKernelGGL(repack_first_weights, dim3(7), dim3(256), 0, st, wf, packed + 1728, 1);
+    hipLaunchKernelGGL(pack_first_fragments, dim3(MF_FRAG_WORDS / 256), dim3(256), 0, st, wf,
+                       reinterpret_cast<uint32_t*>(packed + 2 * 1728));
     STV_CHECK_LAUNCH();
     return STV_OK;
   }

@@ -226,43 +226,68 @@ __global__ __launch_bounds__(1024) void loss_combine_kernel(const float* __restr
                                                             const float* __restrict__ scale, int n_terms,
                                                             float style_w, float content_w,
                                                             float* __restrict__ losses, float* __restrict__ scores) {
-  __shared__ float term[64];
-  __shared__ int kind[64];
+  constexpr int MAXT = 64, NW = 16;
+  __shared__ int s_off[MAXT], s_cnt[MAXT], s_kind[MAXT], s_start[MAXT + 1];
+  __shared__ float s_scale[MAXT], s_term[MAXT];
+  __shared__ double s_part[MAXT][NW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // one wave per loss term (terms beyond 16 take further rounds): the terms reduce side by side
-  // instead of one after the other, each in a fixed order
-  for (int k = wave; k < n_terms; k += 16) {
-    const int off = table[3 * k], cnt = table[3 * k + 1], knd = table[3 * k + 2];
-    const float sc = scale[k];
+  const int nt = n_terms < MAXT ? n_terms : MAXT;        // the schedule never builds more (5 style + 1 content)
+  if (tid < nt) {
+    s_off[tid] = table[3 * tid];
+    s_cnt[tid] = table[3 * tid + 1];
+    s_kind[tid] = table[3 * tid + 2];
+    s_scale[tid] = scale[tid];
+  }
+  for (int i = tid; i < nt * NW; i += 1024) s_part[i / NW][i % NW] = 0.0;
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int k = 0; k < nt; ++k) { s_start[k] = acc; acc += s_cnt[k]; }
+    s_start[nt] = acc;
+  }
+  __syncthreads();
+  // The partials of all terms form one virtual array; wave w reduces its 1/16 of it, term by
+  // term, with every load of its share in flight at once (a lone wave walking an 8192-entry term
+  // four loads at a time was the whole cost of this kernel).  Fixed assignment -> deterministic.
+  const int total = s_start[nt];
+  const int chunk = (total + NW - 1) / NW;
+  const int lo = wave * chunk, hi = (lo + chunk < total) ? lo + chunk : total;
+  for (int k = 0; k < nt; ++k) {
+    const int a = s_start[k] > lo ? s_start[k] : lo;
+    const int b = s_start[k + 1] < hi ? s_start[k + 1] : hi;
+    if (a >= b) continue;                                    // wave-uniform
+    const float* __restrict__ src = parts + s_off[k] - s_start[k];
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int i = lane;
-    for (; i + 192 < cnt; i += 256) {
-      s0 += (double)parts[off + i];
-      s1 += (double)parts[off + i + 64];
-      s2 += (double)parts[off + i + 128];
-      s3 += (double)parts[off + i + 192];
+    int i = a + lane;
+    for (; i + 192 < b; i += 256) {
+      const float v0 = src[i], v1 = src[i + 64], v2 = src[i + 128], v3 = src[i + 192];
+      s0 += (double)v0; s1 += (double)v1; s2 += (double)v2; s3 += (double)v3;
     }
-    for (; i < cnt; i += 64) s0 += (double)parts[off + i];
+    for (; i < b; i += 64) s0 += (double)src[i];
     const double tot = wave_sum_d((s0 + s1) + (s2 + s3));
-    if (lane == 0) {
-      const float v = (float)(tot * (double)sc);
-      losses[k] = v;
-      if (k < 64) { term[k] = v; kind[k] = knd; }
-    }
+    if (lane == 0) s_part[k][wave] = tot;
+  }
+  __syncthreads();
+  if (tid < nt) {
+    double tot = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) tot += s_part[tid][w];
+    const float v = (float)(tot * (double)s_scale[tid]);
+    losses[tid] = v;
+    s_term[tid] = v;
   }
   __syncthreads();
   if (tid == 0) {
     float style = 0.0f, content = 0.0f;
-    for (int k = 0; k < n_terms; ++k) {
-      const float v = (k < 64) ? term[k] : losses[k];
-      if (((k < 64) ? kind[k] : table[3 * k + 2]) == 0) style += v;   // every global round trip here is serial
-      else content += v;
+    for (int k = 0; k < nt; ++k) {
+      if (s_kind[k] == 0) style += s_term[k];
+      else content += s_term[k];
     }
-    const float total = style_w * style + content_w * content;
+    const float total_loss = style_w * style + content_w * content;
     scores[0] = style;
     scores[1] = content;
-    scores[2] = total;
-    scores[3] = (isfinite(style) && isfinite(content) && isfinite(total)) ? 1.0f : 0.0f;
+    scores[2] = total_loss;
+    scores[3] = (isfinite(style) && isfinite(content) && isfinite(total_loss)) ? 1.0f : 0.0f;
   }
 }
 
@@ -379,6 +404,7 @@ extern "C" int stv_content_grad(const void* F, const void* target, void* dF, siz
 extern "C" int stv_loss_combine(const float* parts, const int32_t* table, const float* scale, int n_terms,
                                 float style_w, float content_w, float* losses, float* scores, void* stream) {
   if (!parts || !table || !scale || !losses || !scores || n_terms < 0) return STV_ERR_ARG;
+  if (n_terms > 64) return STV_ERR_ARG;
   hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), parts,
                      table, scale, n_terms, style_w, content_w, losses, scores);
   STV_CHECK_LAUNCH();

@@ -47,8 +47,11 @@ def assert_close(got, ref, dtype, k_terms=1, what=""):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("hw", [(40, 72), (5, 7), (64, 64)])
-def test_conv_first_fwd_and_dgrad(dtype, hw):
+@pytest.mark.parametrize("packed", [False, True])
+@pytest.mark.parametrize("hw", [(40, 72), (5, 7), (64, 64), (33, 100)])
+def test_conv_first_fwd_and_dgrad(dtype, hw, packed):
+    """packed=True: weights prepared once (stv_conv_first_pack); in bf16 the forward then runs on the
+    matrix cores with two-term bf16 splits of image and weights - same tolerance as the VALU kernel."""
     H, W = hw
     cout = 64
     x = rnd((1, 3, H, W), 1, -2, 2)
@@ -56,15 +59,22 @@ def test_conv_first_fwd_and_dgrad(dtype, hw):
     b = rnd((cout,), 3, -0.1, 0.1)
     ref = F.conv2d(x, w, b, padding=1)
     wf = ops.pack_weights_fwd(w).to(DEV)
-    y = ops.conv_first_fwd(x.to(DEV), wf, b.to(DEV), dtype)
+    pk = ops.conv_first_pack(wf) if packed else None
+    y = ops.conv_first_fwd(x.to(DEV), wf, b.to(DEV), dtype, packed=pk)
     assert y.shape == (H, W, cout)
     assert_close(ops.from_nhwc(y), ref, dtype, 27, "conv_first_fwd")
+    if packed and dtype == torch.bfloat16:
+        # the split product is fp32-faithful: what is left is only the bf16 rounding of the output
+        # (two nearly equal values on either side of a rounding boundary differ by one ulp = 2^-7)
+        d = (ops.from_nhwc(y).cpu() - ref.bfloat16().float()).abs() / ref.abs().max()
+        assert float(d.max()) <= 2 ** -7, f"beyond one bf16 ulp of the output scale: {float(d.max()):.2e}"
+        assert float((d > 0).float().mean()) < 0.02, "more than 2 % of the outputs round differently"
     # dgrad: dx = conv_transpose(dy, w)
     dy = rnd((1, cout, H, W), 4)
     dyq = q(dy, dtype)
     xr = x.clone().requires_grad_(True)
     F.conv2d(xr, w, None, padding=1).backward(dyq)
-    dx = ops.conv_first_dgrad(ops.to_nhwc(dy, dtype).to(DEV), wf, 3)
+    dx = ops.conv_first_dgrad(ops.to_nhwc(dy, dtype).to(DEV), wf, 3, packed=pk)
     assert_close(dx, xr.grad, torch.float32, 9 * cout, "conv_first_dgrad")
 
 
