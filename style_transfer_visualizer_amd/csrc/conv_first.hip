@@ -254,18 +254,33 @@ __global__ __launch_bounds__(256) void conv_first_fwd_mfma(const float* __restri
                                                            bf16_t* __restrict__ y, int H, int W) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int CS = 64 + 4;                                 // C-tile pitch (floats)
-  __shared__ __attribute__((aligned(16))) float xs[3 * MF_PLANE + 4];   // [c][row][col], last word = 0
-  __shared__ __attribute__((aligned(16))) float cs[MF_TH * MF_TW * CS];
+  // [c][row][col]; every pixel value is stored already split: bf16 hi in the upper, bf16 lo (the
+  // remainder) in the lower half of the word - split once here, not once per tap it is read for.
+  // Last word = 0.
+  __shared__ __attribute__((aligned(16))) uint32_t xs[3 * MF_PLANE + 4];
+  __shared__ __attribute__((aligned(16))) float cs_all[4 * MF_TW * CS];   // one 32-pixel row block per wave at a time
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int tiles_x = (W + MF_TW - 1) / MF_TW;
-  const int x0 = (blockIdx.x % tiles_x) * MF_TW, y0 = (blockIdx.x / tiles_x) * MF_TH;
-  for (int i = tid; i < 3 * MF_PLANE; i += 256) {
-    const int c = i / MF_PLANE, rem = i - c * MF_PLANE, py = rem / MF_IW, px = rem - py * MF_IW;
-    const int gy = y0 + py - 1, gx = x0 + px - 1;
-    xs[i] = (px < MF_TW + 2 && gy >= 0 && gy < H && gx >= 0 && gx < W) ? x[((size_t)c * H + gy) * W + gx] : 0.0f;
-  }
-  if (tid < 4) xs[3 * MF_PLANE + tid] = 0.0f;
+  const int ntiles = tiles_x * ((H + MF_TH - 1) / MF_TH);
+  // Persistent workgroup: the halo tile of the NEXT image tile is requested (into registers)
+  // before the current one is computed, so the HBM round trip of the loads and the drain of the
+  // stores overlap the split / MFMA / transpose work instead of bracketing it.
+  constexpr int NPRE = (3 * MF_PLANE + 255) / 256;
+  float pre[NPRE];
+  auto request = [&](int t) {
+    const int tx0 = (t % tiles_x) * MF_TW, ty0 = (t / tiles_x) * MF_TH;
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) {
+      const int i = k * 256 + tid;
+      const int c = i / MF_PLANE, rem = i - c * MF_PLANE, py = rem / MF_IW, px = rem - py * MF_IW;
+      const int gy = ty0 + py - 1, gx = tx0 + px - 1;
+      const bool ok = i < 3 * MF_PLANE && px < MF_TW + 2 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      pre[k] = ok ? x[((size_t)c * H + gy) * W + gx] : 0.0f;
+    }
+  };
+  request(blockIdx.x);
+  if (tid < 4) xs[3 * MF_PLANE + tid] = 0u;
   // weight fragments: [hi|lo][kstep][nt] for this lane, 16 bytes each
   bf16x8v bw[2][2][2];
 #pragma unroll
@@ -287,6 +302,21 @@ __global__ __launch_bounds__(256) void conv_first_fwd_mfma(const float* __restri
       const int tap = k / 3, c = k - tap * 3;
       koff[ks][e] = (k < 27) ? c * MF_PLANE + (tap / 3) * MF_IW + (tap % 3) : -1;
     }
+  const int cv = lane & 7;                                  // 8 vectors of 8 channels per pixel
+  float bv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bv[e] = bias ? bias[cv * 8 + e] : 0.0f;
+  float* cs = cs_all + wave * (MF_TW * CS);
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+  const int x0 = (t % tiles_x) * MF_TW, y0 = (t / tiles_x) * MF_TH;
+  __syncthreads();                       // every wave is done gathering from the previous tile
+#pragma unroll
+  for (int k = 0; k < NPRE; ++k)
+    if (k * 256 + tid < 3 * MF_PLANE) {
+      const bf16_t hi = f32_to_bf16(pre[k]);
+      xs[k * 256 + tid] = ((uint32_t)hi << 16) | (uint32_t)f32_to_bf16(pre[k] - bf16_to_f32(hi));
+    }
+  if (t + (int)gridDim.x < ntiles) request(t + gridDim.x);
   __syncthreads();
   f32x16 acc[2][2];
 #pragma unroll
@@ -303,15 +333,14 @@ __global__ __launch_bounds__(256) void conv_first_fwd_mfma(const float* __restri
       uint32_t hi4[4], lo4[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        float v[2];
+        uint32_t w[2];
 #pragma unroll
         for (int e2 = 0; e2 < 2; ++e2) {
           const int o = koff[ks][2 * q + e2];
-          v[e2] = xs[o >= 0 ? base + o : 3 * MF_PLANE];
+          w[e2] = xs[o >= 0 ? base + o : 3 * MF_PLANE];
         }
-        const bf16_t h0 = f32_to_bf16(v[0]), h1 = f32_to_bf16(v[1]);
-        hi4[q] = (uint32_t)h0 | ((uint32_t)h1 << 16);
-        lo4[q] = pack_bf16x2(v[0] - bf16_to_f32(h0), v[1] - bf16_to_f32(h1));
+        hi4[q] = __builtin_amdgcn_perm(w[1], w[0], 0x07060302u);    // (hi of w1) : (hi of w0)
+        lo4[q] = __builtin_amdgcn_perm(w[1], w[0], 0x05040100u);    // (lo of w1) : (lo of w0)
       }
       const bf16x8v a_hi = __builtin_bit_cast(bf16x8v, (u32x4){hi4[0], hi4[1], hi4[2], hi4[3]});
       const bf16x8v a_lo = __builtin_bit_cast(bf16x8v, (u32x4){lo4[0], lo4[1], lo4[2], lo4[3]});
@@ -323,34 +352,120 @@ __global__ __launch_bounds__(256) void conv_first_fwd_mfma(const float* __restri
       }
     }
   }
-  // accumulators -> C tile (each wave its own 64 pixel rows), then 16-byte NHWC stores
+  // accumulators -> this wave's strip of the C tile (one 32-pixel row at a time: LDS stays small
+  // enough for four workgroups per CU, whose load / compute / store phases then overlap), then
+  // 16-byte NHWC stores.  A wave's LDS operations are in order: no barrier between write and read.
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = (wave * 2 + mt) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        cs[row * CS + nt * 32 + r] = acc[mt][nt][i];
+      for (int i = 0; i < 16; ++i) cs[((i & 3) + 8 * (i >> 2) + 4 * h) * CS + nt * 32 + r] = acc[mt][nt][i];
+    const int gy = y0 + wave * 2 + mt;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int px = it * 8 + (lane >> 3);
+      const int gx = x0 + px;
+      float val[8];
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(cs + px * CS + cv * 8 + qq * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) val[qq * 4 + e] = t[e] + bv[qq * 4 + e];
       }
-  __syncthreads();
-  const int cv = tid & 7;                                   // 8 vectors of 8 channels per pixel
-  float bv[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) bv[e] = bias ? bias[cv * 8 + e] : 0.0f;
-#pragma unroll
-  for (int it = 0; it < MF_TH * MF_TW * 8 / 256; ++it) {
-    const int pix = (it * 256 + tid) >> 3;
-    const int gy = y0 + (pix >> 5), gx = x0 + (pix & 31);
-    if (gy >= H || gx >= W) continue;
-    float val[8];
-#pragma unroll
-    for (int qq = 0; qq < 2; ++qq) {
-      const f32x4 t = *reinterpret_cast<const f32x4*>(cs + pix * CS + cv * 8 + qq * 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) val[qq * 4 + e] = t[e] + bv[qq * 4 + e];
+      if (gy < H && gx < W) *reinterpret_cast<u32x4*>(y + ((size_t)gy * W + gx) * 64 + cv * 8) = pack16<bf16_t>(val);
     }
-    *reinterpret_cast<u32x4*>(y + ((size_t)gy * W + gx) * 64 + cv * 8) = pack16<bf16_t>(val);
+  }
+  }   // tiles
+#endif
+}
+
+// ---- input gradient on the matrix cores (bf16 activations) -----------------------------------------
+// dx[c][p] = sum_tap sum_n dy[p + off(tap)][n] * wd[tap][c][n]: M = pixels, N = 3 (padded to the 16
+// columns of v_mfma_f32_16x16x32_bf16), K = 9 x 64.  dy is bf16 as stored; the weights are split in
+// two bf16 terms so the product stays fp32-faithful.  Only 12 lanes of a weight fragment are
+// non-zero (3 channels x 4 k-groups), so the fragment table is 7 KB of LDS.
+constexpr int DG_TH = 8, DG_TW = 32, DG_IW = DG_TW + 2, DG_PITCH = 128 + 16;
+constexpr int DG_TILE_BYTES = (DG_TH + 2) * DG_IW * DG_PITCH;
+constexpr int DG_FRAGS = 9 * 2 * 2 * 12;                    // [tap][kstep][hi|lo][c * 4 + g], 16 bytes each
+constexpr int DG_FRAG_WORDS = DG_FRAGS * 4;
+
+__global__ void pack_first_dgrad_fragments(const float* __restrict__ wf, uint32_t* __restrict__ frag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;        // one bf16 pair per thread
+  if (i >= DG_FRAG_WORDS) return;
+  const int q = i & 3, ent = (i >> 2) % 12, rest = (i >> 2) / 12;
+  const int part = rest & 1, ks = (rest >> 1) & 1, tap = rest >> 2;
+  const int c = ent >> 2, g = ent & 3;
+  uint32_t out = 0;
+  for (int e2 = 0; e2 < 2; ++e2) {
+    const int n = ks * 32 + 8 * g + 2 * q + e2;
+    const float v = wf[((8 - tap) * 64 + n) * 3 + c];         // flipped taps: the read offset becomes +off(tap)
+    const bf16_t hi = f32_to_bf16(v);
+    const bf16_t lo = f32_to_bf16(v - bf16_to_f32(hi));
+    out |= (uint32_t)(part ? lo : hi) << (16 * e2);
+  }
+  frag[i] = out;
+}
+
+__global__ __launch_bounds__(256) void conv_first_dgrad_mfma(const bf16_t* __restrict__ dy,
+                                                             const uint32_t* __restrict__ frag,
+                                                             float* __restrict__ dx, int H, int W) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* tile = smem;
+  u32x4* wtab = reinterpret_cast<u32x4*>(smem + DG_TILE_BYTES);          // DG_FRAGS entries + one zero entry
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int tiles_x = (W + DG_TW - 1) / DG_TW;
+  const int x0 = (blockIdx.x % tiles_x) * DG_TW, y0 = (blockIdx.x / tiles_x) * DG_TH;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  for (int i = tid; i < (DG_TH + 2) * DG_IW * 8; i += 256) {
+    const int p = i >> 3, v = i & 7;
+    const int gy = y0 + p / DG_IW - 1, gx = x0 + p % DG_IW - 1;
+    const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+    *reinterpret_cast<u32x4*>(tile + p * DG_PITCH + v * 16) =
+        ok ? *reinterpret_cast<const u32x4*>(dy + ((size_t)gy * W + gx) * 64 + v * 8) : zero4;
+  }
+  for (int i = tid; i < DG_FRAGS; i += 256) wtab[i] = *reinterpret_cast<const u32x4*>(frag + 4 * i);
+  if (tid == 0) wtab[DG_FRAGS] = zero4;
+  __syncthreads();
+  typedef __attribute__((ext_vector_type(4))) float acc_t;
+  acc_t acc[4];
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) acc[mb] = acc_t{0.0f, 0.0f, 0.0f, 0.0f};
+  // B column = lane & 15: columns 0..2 are the three image channels, the rest multiply zeros
+  const int ent = (r < 3) ? r * 4 + g : -1;
+#pragma unroll 1
+  for (int tap = 0; tap < 9; ++tap) {
+    const int dyo = tap / 3, dxo = tap - dyo * 3;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int fb = ((tap * 2 + ks) * 2) * 12;
+      const bf16x8v b_hi = __builtin_bit_cast(bf16x8v, wtab[ent >= 0 ? fb + ent : DG_FRAGS]);
+      const bf16x8v b_lo = __builtin_bit_cast(bf16x8v, wtab[ent >= 0 ? fb + 12 + ent : DG_FRAGS]);
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) {
+        const int row = wave * 2 + (mb >> 1) + dyo, col = (mb & 1) * 16 + r + dxo;
+        const bf16x8v a = __builtin_bit_cast(
+            bf16x8v, *reinterpret_cast<const u32x4*>(tile + (row * DG_IW + col) * DG_PITCH + ks * 64 + g * 16));
+        acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b_lo, acc[mb], 0, 0, 0);
+        acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b_hi, acc[mb], 0, 0, 0);
+      }
+    }
+  }
+  // D: column (lane & 15) = channel, rows 4g..4g+3 = pixels of the 16-pixel block
+  if (r < 3) {
+    const size_t plane = (size_t)H * W;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      const int gy = y0 + wave * 2 + (mb >> 1);
+      if (gy >= H) continue;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int gx = x0 + (mb & 1) * 16 + 4 * g + i;
+        if (gx < W) dx[r * plane + (size_t)gy * W + gx] = acc[mb][i];
+      }
+    }
   }
 #endif
 }
@@ -425,7 +540,8 @@ int fwd_typed(const float* x, const float* wf, const float* packed, const float*
               int cin, int cout, hipStream_t st) {
   if (cin == 3 && cout == 64 && packed && std::is_same<T, bf16_t>::value && !getenv("STV_FIRST_VALU")) {
     const int tiles = ceil_div(W, MF_TW) * ceil_div(H, MF_TH);
-    hipLaunchKernelGGL(conv_first_fwd_mfma, dim3(tiles), dim3(256), 0, st, x,
+    const int grid = tiles < 4 * 256 ? tiles : 4 * 256;       // four resident workgroups per CU walk the tiles
+    hipLaunchKernelGGL(conv_first_fwd_mfma, dim3(grid), dim3(256), 0, st, x,
                        reinterpret_cast<const uint32_t*>(packed + 2 * 1728), bias, static_cast<bf16_t*>(y), H, W);
     STV_CHECK_LAUNCH();
     return STV_OK;
@@ -460,6 +576,14 @@ int fwd_typed(const float* x, const float* wf, const float* packed, const float*
 template <typename T>
 int dgrad_typed(const void* dy, const float* wf, const float* packed, float* dx, int H, int W, int cin, int cout,
                 hipStream_t st) {
+  if (cin == 3 && cout == 64 && packed && std::is_same<T, bf16_t>::value && !getenv("STV_FIRST_VALU")) {
+    const int tiles = ceil_div(W, DG_TW) * ceil_div(H, DG_TH);
+    constexpr int lds = DG_TILE_BYTES + (DG_FRAGS + 1) * 16;
+    hipLaunchKernelGGL(conv_first_dgrad_mfma, dim3(tiles), dim3(256), lds, st, static_cast<const bf16_t*>(dy),
+                       reinterpret_cast<const uint32_t*>(packed + 2 * 1728 + MF_FRAG_WORDS), dx, H, W);
+    STV_CHECK_LAUNCH();
+    return STV_OK;
+  }
   if (cin == 3 && cout == 64) {
     const float* wd = packed ? packed + 1728 : nullptr;
     if (!wd) {
@@ -501,7 +625,7 @@ int dgrad_typed(const void* dy, const float* wf, const float* packed, float* dx,
 
 extern "C" size_t stv_conv_first_packed_bytes(int cin, int cout) {
   const size_t plain = (size_t)2 * 9 * (size_t)(cin > 0 ? cin : 0) * (size_t)(cout > 0 ? cout : 0) * sizeof(float);
-  return (cin == 3 && cout == 64) ? plain + (size_t)MF_FRAG_WORDS * 4 : plain;   // + matrix-core weight fragments
+  return (cin == 3 && cout == 64) ? plain + (size_t)(MF_FRAG_WORDS + DG_FRAG_WORDS) * 4 : plain;   // + matrix-core fragments
 }
 
 extern "C" int stv_conv_first_pack(const float* wf, float* packed, int cin, int cout, void* stream) {
@@ -512,6 +636,8 @@ extern "C" int stv_conv_first_pack(const float* wf, float* packed, int cin, int 
     hipLaunchKernelGGL(repack_first_weights, dim3(7), dim3(256), 0, st, wf, packed + 1728, 1);
     hipLaunchKernelGGL(pack_first_fragments, dim3(MF_FRAG_WORDS / 256), dim3(256), 0, st, wf,
                        reinterpret_cast<uint32_t*>(packed + 2 * 1728));
+    hipLaunchKernelGGL(pack_first_dgrad_fragments, dim3((DG_FRAG_WORDS + 255) / 256), dim3(256), 0, st, wf,
+                       reinterpret_cast<uint32_t*>(packed + 2 * 1728 + MF_FRAG_WORDS));
     STV_CHECK_LAUNCH();
     return STV_OK;
   }

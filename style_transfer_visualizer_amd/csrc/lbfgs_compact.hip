@@ -432,7 +432,9 @@ __global__ __launch_bounds__(256) void pass_b_kernel(float* __restrict__ x, cons
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[u][e] = cg * gv[u][e];
   }
-  for (int jj = 0; jj < m; ++jj) {
+  // newest pair first: pass A walked the history oldest-to-newest just before, so its tail is what
+  // the Infinity Cache still holds
+  for (int jj = m - 1; jj >= 0; --jj) {
     const int slot = (head + jj) % S;
     const float cs = st->cs[slot], cy = st->cy[slot];
     const float* __restrict__ sj = w.S + (size_t)slot * nn;
