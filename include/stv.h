@@ -102,6 +102,14 @@ int stv_conv_igemm(const void* x, const void* w, const float* bias, const void* 
                    void* y, int H, int W, int cin, int cout, int taps, int flags,
                    int dtype, void* stream);
 
+/* Forward 3x3 conv that also emits MaxPool2d(2,2) of its output (`y_pool`,
+ * NHWC [H/2][W/2][cout]) from the same epilogue: replaces the conv2d + relu +
+ * max_pool2d run of `x = block(x)` (core_model.py:316) where a pool follows the
+ * conv.  Matrix-core shapes only (stv_conv_config >= 0), else STV_ERR_ARG and the
+ * caller pools with stv_maxpool_fwd.  flags: RELU_IN, RELU_OUT, W_BLOCKED. */
+int stv_conv_igemm_pool(const void* x, const void* w, const float* bias, void* y, void* y_pool,
+                        int H, int W, int cin, int cout, int flags, int dtype, void* stream);
+
 /* Which tile the dispatcher picks for a shape: -1 = scalar fallback (channel counts not a
  * multiple of the MFMA K-slice), else 0..3 = {8x128, 8x64, 4x128, 4x64} (rows x couts) and
  * 4 = 4x64 with K split over two wave groups, 5 = 8x64 with a two-deep LDS ring. */
@@ -188,7 +196,8 @@ enum {
   STV_OP_MEMSET
 };
 /* Operands follow the direct entry points' argument order (inputs p0.., outputs q0..).
- * CONV_FIRST_FWD takes the optional stv_conv_first_pack buffer in p3, CONV_FIRST_DGRAD in p2. */
+ * CONV_FIRST_FWD takes the optional stv_conv_first_pack buffer in p3, CONV_FIRST_DGRAD in p2;
+ * CONV with q1 set runs stv_conv_igemm_pool (q1 = pooled output). */
 typedef struct {
   int32_t op, dtype, flags, taps;
   int32_t H, W, cin, cout;

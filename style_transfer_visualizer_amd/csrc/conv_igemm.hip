@@ -112,6 +112,7 @@ struct ConvArgs {
   const void* ref;
   void* y;
   int H, W, cin, cout, flags;
+  void* pool;   // optional second output: MaxPool2d(2,2) of y, [H/2][W/2][cout]
 };
 
 template <typename T> struct Frag;
@@ -432,6 +433,38 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
     }
     __builtin_amdgcn_raw_buffer_store_b128(pack16<T>(val), rs_y, o_off[it], 0, 0);   // OOB lanes are dropped
   }
+  // Fused MaxPool2d(2,2) (forward convs in front of a pool): the 2x2 windows of this tile are
+  // complete in the C tile (TH and the tile origin are even), max / bias / ReLU commute, so the
+  // pooled map costs four more LDS reads per output vector instead of a second pass over HBM.
+  if (a.pool != nullptr) {
+    const int Hp = a.H >> 1, Wp = a.W >> 1;
+    const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(a.pool, 0, Hp * Wp * a.cout * (int)sizeof(T), 0x00020000);
+    constexpr int PVEC = (C::BM / 4) * VPR;
+#pragma unroll
+    for (int it = 0; it < (PVEC + C::THREADS - 1) / C::THREADS; ++it) {
+      const int idx = it * C::THREADS + tid;
+      const int q = idx / VPR;                          // pooled pixel of the tile: 16 per row
+      const int qy = q >> 4, qx = q & 15;
+      const int gyp = (y0 >> 1) + qy, gxp = (x0 >> 1) + qx;
+      const bool ok = idx < PVEC && gyp < Hp && gxp < Wp && n < a.cout;
+      float val[kVec];
+#pragma unroll
+      for (int qq = 0; qq < kVec / 4; ++qq) {
+        const float* src = cs + ((2 * qy) * 32 + 2 * qx) * C::CS + cv * kVec + qq * 4;
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(src);
+        const f32x4 t1 = *reinterpret_cast<const f32x4*>(src + C::CS);
+        const f32x4 t2 = *reinterpret_cast<const f32x4*>(src + 32 * C::CS);
+        const f32x4 t3 = *reinterpret_cast<const f32x4*>(src + 33 * C::CS);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float m = fmaxf(fmaxf(t0[e], t1[e]), fmaxf(t2[e], t3[e])) + bias_v[qq][e];
+          val[qq * 4 + e] = relu_out ? fmaxf(m, 0.0f) : m;
+        }
+      }
+      const uint32_t off = ok ? (uint32_t)(((gyp * Wp + gxp) * a.cout + n) * (int)sizeof(T)) : kOob;
+      __builtin_amdgcn_raw_buffer_store_b128(pack16<T>(val), rs_p, off, 0, 0);
+    }
+  }
   STV_STAMP(4);
 #endif
 }
@@ -582,7 +615,7 @@ int tune_typed(int H, int W, int cin, int cout, int taps, hipStream_t st) {
   const size_t words = (bx + bw) / 4;
   hipLaunchKernelGGL(tune_fill_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st,
                      reinterpret_cast<uint32_t*>(buf), words, 0x9E3779B9u);
-  ConvArgs a{buf, buf + bx, nullptr, nullptr, buf + bx + bw, H, W, cin, cout, STV_W_BLOCKED};
+  ConvArgs a{buf, buf + bx, nullptr, nullptr, buf + bx + bw, H, W, cin, cout, STV_W_BLOCKED, nullptr};
   if (taps == 1) a.flags = 0;
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
@@ -651,11 +684,24 @@ extern "C" int stv_conv_igemm(const void* x, const void* w, const float* bias, c
   // the direct fallback (shapes the matrix-core tiling does not cover) reads plain weights only
   if ((flags & STV_W_BLOCKED) && choose_cfg(H, W, cin, cout, dtype == STV_F32 ? 4 : 2, taps) < 0) return STV_ERR_ARG;
   if ((size_t)H * W * (size_t)(cin > cout ? cin : cout) >= (size_t)1 << 31) return STV_ERR_ARG;
-  ConvArgs a{x, w, bias, ref, y, H, W, cin, cout, flags};
+  ConvArgs a{x, w, bias, ref, y, H, W, cin, cout, flags, nullptr};
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dtype == STV_F32)
     return taps == 9 ? launch_typed<float, 9>(a, st) : launch_typed<float, 1>(a, st);
   if (dtype == STV_BF16)
     return taps == 9 ? launch_typed<bf16_t, 9>(a, st) : launch_typed<bf16_t, 1>(a, st);
   return STV_ERR_ARG;
+}
+
+extern "C" int stv_conv_igemm_pool(const void* x, const void* w, const float* bias, void* y, void* y_pool,
+                                   int H, int W, int cin, int cout, int flags, int dtype, void* stream) {
+  if (!x || !w || !y || !y_pool || H <= 1 || W <= 1 || cin <= 0 || cout <= 0) return STV_ERR_ARG;
+  if (flags & (STV_MASK | STV_ACCUM)) return STV_ERR_ARG;                     // forward convolutions only
+  if ((size_t)H * W * (size_t)(cin > cout ? cin : cout) >= (size_t)1 << 31) return STV_ERR_ARG;
+  if (dtype != STV_F32 && dtype != STV_BF16) return STV_ERR_ARG;
+  // the fused pool lives in the matrix-core kernel's epilogue: other shapes pool separately
+  if (choose_cfg(H, W, cin, cout, dtype == STV_F32 ? 4 : 2, 9) < 0) return STV_ERR_ARG;
+  ConvArgs a{x, w, bias, nullptr, y, H, W, cin, cout, flags, y_pool};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  return dtype == STV_F32 ? launch_typed<float, 9>(a, st) : launch_typed<bf16_t, 9>(a, st);
 }

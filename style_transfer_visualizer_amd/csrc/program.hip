@@ -30,6 +30,9 @@ int run_op(const stv_op_t& o, void* st) {
       return stv_conv_first_dgrad(o.p0, static_cast<const float*>(o.p1), static_cast<float*>(o.q0), o.H,
                                   o.W, o.cin, o.cout, o.dtype, st);
     case STV_OP_CONV:
+      if (o.q1)    // forward conv with the following MaxPool2d(2,2) fused into its epilogue
+        return stv_conv_igemm_pool(o.p0, o.p1, static_cast<const float*>(o.p2), o.q0, o.q1, o.H, o.W, o.cin,
+                                   o.cout, o.flags, o.dtype, st);
       return stv_conv_igemm(o.p0, o.p1, static_cast<const float*>(o.p2), o.p3, o.q0, o.H, o.W, o.cin,
                             o.cout, o.taps, o.flags, o.dtype, st);
     case STV_OP_POOL_FWD:

@@ -161,6 +161,29 @@ def conv_igemm(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = Non
     return out
 
 
+def conv_igemm_pool(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None, flags: int = 0,
+                    out: torch.Tensor | None = None, pool_out: torch.Tensor | None = None,
+                    ) -> tuple[torch.Tensor, torch.Tensor]:
+    """3x3 conv (+bias, +ReLU by flag) and MaxPool2d(2,2) of its output in one launch (stv_conv_igemm_pool)."""
+    H, W, cin = x.shape
+    if w.dim() == 4:
+        taps, nck, cout, ck = w.shape
+        flags |= W_BLOCKED
+    else:
+        taps, cout, _ = w.shape
+    if taps != 9:
+        msg = "the fused pool needs a 3x3 convolution"
+        raise RuntimeError(msg)
+    if out is None:
+        out = torch.empty(H, W, cout, device=x.device, dtype=x.dtype)
+    if pool_out is None:
+        pool_out = torch.empty(H // 2, W // 2, cout, device=x.device, dtype=x.dtype)
+    lib = _lib.load()
+    _lib.check(lib.stv_conv_igemm_pool(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), _ptr(pool_out), H, W, cin, cout,
+                                       flags, dtype_code(x.dtype), _stream()), "stv_conv_igemm_pool")
+    return out, pool_out
+
+
 # ---- pool / relu --------------------------------------------------------------
 
 def maxpool_fwd(x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:

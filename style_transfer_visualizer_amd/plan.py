@@ -213,16 +213,30 @@ class Schedule:
         """Forward schedule; ``after_node(node)`` may return extra ops to splice in right after a
         node's op (loss-side work that only needs that node's output)."""
         out = []
-        for nd in self.nodes:
+        fuse_pool = os.environ.get("STV_FUSE_POOL", "1") != "0"      # A/B knob
+        fused: set[int] = set()          # pool nodes whose work rides in the preceding conv's epilogue
+        for k, nd in enumerate(self.nodes):
             d = nd.dst
+            # conv (ReLU in its epilogue) -> pool: one launch writes both maps.  Only where the conv
+            # runs on the matrix cores, and not when the conv output itself is tapped pre-ReLU.
+            nxt = self.nodes[k + 1] if k + 1 < len(self.nodes) else None
+            pool_dst = None
+            if (fuse_pool and nd.kind == "conv" and nxt is not None and nxt.kind == "pool" and nxt.src is d
+                    and d.relu_fused and nd.wf.dim() == 4 and d.act.is_cuda):
+                pool_dst = nxt.dst.act
+                fused.add(id(nxt))
+            if id(nd) in fused:
+                if after_node is not None:
+                    out += after_node(nd)
+                continue
             if nd.kind == "conv_first":
                 out.append(self._op(op=OP_CONV_FIRST_FWD, p0=x, p1=nd.wf, p2=nd.bias, p3=nd.wb, q0=d.act,
                                     H=d.H, W=d.W, cin=nd.cin, cout=d.C))
             elif nd.kind == "conv":
                 flags = ((RELU_IN if nd.relu_in else 0) | (RELU_OUT if d.relu_fused else 0)
                          | (W_BLOCKED if nd.wf.dim() == 4 else 0))
-                out.append(self._op(op=OP_CONV, p0=nd.src.act, p1=nd.wf, p2=nd.bias, q0=d.act, H=d.H, W=d.W,
-                                    cin=nd.cin, cout=d.C, taps=9, flags=flags))
+                out.append(self._op(op=OP_CONV, p0=nd.src.act, p1=nd.wf, p2=nd.bias, q0=d.act, q1=pool_dst, H=d.H,
+                                    W=d.W, cin=nd.cin, cout=d.C, taps=9, flags=flags))
             elif nd.kind == "pool":
                 out.append(self._op(op=OP_POOL_FWD, p0=nd.src.act, q0=d.act, H=nd.src.H, W=nd.src.W, cin=d.C))
             else:

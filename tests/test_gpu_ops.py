@@ -131,6 +131,29 @@ def test_conv_igemm_forward(dtype, case, flags, blocked):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [None, 0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("case", [(64, 64, 33, 70), (128, 128, 16, 40), (64, 128, 9, 33), (256, 256, 8, 8)])
+def test_conv_igemm_with_fused_maxpool(dtype, cfg, case, monkeypatch):
+    """One launch writes relu(conv) and MaxPool2d(2,2) of it (odd sizes drop the last row / column like torch)."""
+    cin, cout, H, W = case
+    if cfg is not None:
+        if cout <= 64 and cfg in (0, 2):
+            pytest.skip("128-channel tiles need more than 64 output channels")
+        monkeypatch.setenv("STV_CONV_CFG", str(cfg))
+    x = rnd((1, cin, H, W), 51)
+    w = rnd((cout, cin, 3, 3), 52, -1, 1) * (2.0 / (9 * cin)) ** 0.5
+    b = rnd((cout,), 53, -0.2, 0.2)
+    ref = F.relu(F.conv2d(q(x, dtype), q(w, dtype), b, padding=1))
+    wp = ops.block_weights(ops.pack_weights_fwd(w).to(dtype).to(DEV))
+    y, yp = ops.conv_igemm_pool(ops.to_nhwc(x, dtype).to(DEV), wp, b.to(DEV), flags=ops.RELU_OUT)
+    assert_close(ops.from_nhwc(y), ref, dtype, 9 * cin, f"conv {case}")
+    assert yp.shape == (H // 2, W // 2, cout)
+    # the pooled map is exactly the pool of the stored map (same rounding, max commutes with it)
+    want = F.max_pool2d(ops.from_nhwc(y).cpu(), 2, 2)
+    assert torch.equal(ops.from_nhwc(yp).cpu(), want)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("case", [(128, 128, 21, 70), (64, 64, 9, 33), (48, 136, 12, 40), (512, 128, 8, 8)])
 def test_conv_igemm_every_tile_config(dtype, cfg, case, monkeypatch):
