@@ -438,13 +438,15 @@ class StyleContentModel(nn.Module):
         content = [losses[eng.n_style + i] for i in range(eng.n_content)]
         return style, content
 
-    def loss_and_grad(self, x: torch.Tensor, style_w: float, content_w: float,
+    def loss_and_grad(self, x: torch.Tensor, style_w: float, content_w: float, *, live_scores: bool = False,
                       ) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """Fused step: writes d(style_w*S + content_w*C)/dx into ``x.grad``.
 
         Equivalent to reference optimization.py:292-313 (forward, weighted sum,
         ``loss.backward()``) in one command-buffer launch with no host sync.
-        Returns 0-d device tensors (style_score, content_score, total).
+        Returns 0-d device tensors (style_score, content_score, total).  With
+        ``live_scores`` they are views of the engine's score buffer - valid until the
+        next evaluation, one copy kernel less per step (the runner consumes them at once).
         """
         self._require_targets()
         eng = self._engine_for(x)
@@ -458,7 +460,7 @@ class StyleContentModel(nn.Module):
             self._grad_buf = grad
         eng.loss_and_grad(x.detach(), grad, float(style_w), float(content_w))
         x.grad = grad
-        scores = eng.scores.clone()
+        scores = eng.scores if live_scores else eng.scores.clone()
         return scores[0], scores[1], scores[2]
 
 

@@ -65,8 +65,10 @@ class LossAccumulator:
     def accumulate(self, step_idx: int, style_loss: torch.Tensor, content_loss: torch.Tensor,
                    total_loss: torch.Tensor, *, force: bool = False) -> LoggedLoss | None:
         """Record one step; return host scalars only at the logging cadence."""
-        triple = torch.stack((style_loss.detach().reshape(()), content_loss.detach().reshape(()),
-                              total_loss.detach().reshape(())))
+        triple = self._adjacent(style_loss, content_loss, total_loss)
+        if triple is None:
+            triple = torch.stack((style_loss.detach().reshape(()), content_loss.detach().reshape(()),
+                                  total_loss.detach().reshape(())))
         self._pending = (step_idx, triple)
         if self._track:
             if self._ring is None:
@@ -79,6 +81,24 @@ class LossAccumulator:
         if force or step_idx % self._log_every == 0:
             return self._sync_pending()
         return None
+
+    @staticmethod
+    def _adjacent(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor) -> torch.Tensor | None:
+        """The three scalars as one [3] view when they already sit side by side in one buffer (the
+        fused step returns views of its score vector): saves the stack kernel."""
+        try:
+            if not (a.numel() == b.numel() == c.numel() == 1 and a.dtype == b.dtype == c.dtype
+                    and a.device == b.device == c.device):
+                return None
+            base = a.untyped_storage().data_ptr()
+            if b.untyped_storage().data_ptr() != base or c.untyped_storage().data_ptr() != base:
+                return None
+            o = a.storage_offset()
+            if b.storage_offset() != o + 1 or c.storage_offset() != o + 2:
+                return None
+            return torch.as_strided(a.detach(), (3,), (1,), o)
+        except RuntimeError:
+            return None
 
     def latest(self) -> LoggedLoss | None:
         """Most recent host-synced scalars."""

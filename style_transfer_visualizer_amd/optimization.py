@@ -145,6 +145,7 @@ class OptimizationRunner:
         self._pending_step_tensors: StepTensors | None = None
         self._closure_calls = 0
         self._fused = callable(getattr(model, "loss_and_grad", None))
+        self._live_scores: bool | None = None
 
     # ------------------------------------------------------------------ properties
     @property
@@ -264,7 +265,7 @@ class OptimizationRunner:
         oc = self.config.optimization
         self.optimizer.zero_grad()
         if self._fused:
-            style_score, content_score, loss = self.model.loss_and_grad(self.input_img, oc.style_w, oc.content_w)
+            style_score, content_score, loss = self._fused_eval(oc.style_w, oc.content_w)
         else:
             style_losses, content_losses = self.model(self.input_img)
             zero = torch.zeros((), device=self.input_img.device, dtype=self.input_img.dtype)
@@ -275,6 +276,19 @@ class OptimizationRunner:
             self._check_finite(style_score, content_score, loss, step_idx)
         return StepTensors(step=step_idx, style_score=style_score, content_score=content_score, total_loss=loss)
 
+    def _fused_eval(self, style_w: float, content_w: float) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """The model's fused step; its scores are recorded before the next evaluation, so views of the
+        live score buffer are enough where the model offers them (models without the keyword: plain call)."""
+        if self._live_scores is None:
+            import inspect
+            try:
+                self._live_scores = "live_scores" in inspect.signature(self.model.loss_and_grad).parameters
+            except (TypeError, ValueError):
+                self._live_scores = False
+        if self._live_scores:
+            return self.model.loss_and_grad(self.input_img, style_w, content_w, live_scores=True)
+        return self.model.loss_and_grad(self.input_img, style_w, content_w)
+
     def _final_loss_tensor(self) -> torch.Tensor:
         if self._last_loss_tensor is not None:
             return self._last_loss_tensor.detach()
@@ -283,7 +297,7 @@ class OptimizationRunner:
     # ----------------------------------------------------------------- per step
     def _finalize_step(self, tensors: StepTensors) -> None:
         self._step_index = tensors.step
-        self._last_loss_tensor = tensors.total_loss.detach()
+        self._last_loss_tensor = tensors.total_loss.detach()      # a view of the live scores on the fused path: "last" by construction
         logged = self._record_losses(tensors)
         if logged is not None:
             self._latest_logged = logged
