@@ -24,6 +24,9 @@
 //              k = 4h..4h+3 (any k permutation is fine as long as A and B agree).
 // ReLU-on-load (STV_RELU_IN) is one packed integer max per fragment dword (a negative bf16 / fp32
 // is a negative integer), against a scalar that is 0 or INT_MIN - branch-free.
+// The MFMAs take the weights as the row operand, so an accumulator lane holds 16 channels of one
+// pixel; the epilogue (bias, ReLU, ReLU mask, accumulate, the optional fused 2x2 max-pool) runs in
+// registers and v_permlane32_swap pairs the half-waves' channel groups into 16-byte stores.
 //
 // The same kernel computes the input gradient (dgrad) when handed the flipped, transposed
 // weights, and the Gram backward product dF = F * S as a 1x1 conv.
@@ -179,20 +182,22 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
   // ReLU-on-load floor: integer max with 0 clears negative elements, with INT_MIN it is the identity
   const uint32_t relu_floor = (a.flags & STV_RELU_IN) ? 0u : (sizeof(T) == 2 ? 0x80008000u : 0x80000000u);
   STV_STAMP(0);
-  // this thread's slice of the bias (all its output vectors share one channel group): requested
-  // first, a global round trip is ~2 us on a busy chip and nothing else in the epilogue waits
-  constexpr int VPR = C::BN / kVec;  // output vectors per pixel of the tile
-  const int cv = tid % VPR;
-  const int n = n0 + cv * kVec;
+  // Accumulator layout (MFMA roles: rows = output channels, columns = pixels): this lane owns
+  // pixel r of its wave's row blocks and, per 32-channel block, channels 8j + 4h + e (j, e < 4).
+  // Its bias values are requested first: a global round trip is ~2 us on a busy chip.
+  const int wm_ = (wave / C::WN), wn_ = (wave % C::WN);
   const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.bias), 0, a.bias != nullptr ? a.cout * 4 : 0, 0x00020000);
-  f32x4 bias_v[kVec / 4];           // channels past cout (and a null bias) read as zero
+  f32x4 bias_v[C::NT][4];           // channels past cout (and a null bias) read as zero
 #pragma unroll
-  for (int q = 0; q < kVec / 4; ++q) {
-    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (uint32_t)((n + q * 4) * 4), 0, 0);
+  for (int nt = 0; nt < C::NT; ++nt)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) bias_v[q][e] = __uint_as_float(t[e]);
-  }
+    for (int j = 0; j < 4; ++j) {
+      const int nn = n0 + wn_ * (C::NT * 32) + nt * 32 + 8 * j + 4 * (lane >> 5);
+      const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (uint32_t)(nn * 4), 0, 0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bias_v[nt][j][e] = __uint_as_float(t[e]);
+    }
 
   // ---- DMA pieces of this wave: per-lane source byte offsets (out of range -> zero fill) ----
   constexpr uint32_t kOob = 0x80000000u;   // >= num_records for every tensor this kernel accepts
@@ -308,7 +313,7 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
       for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < C::NT; ++nt) mma<T>(af[dx & 1][mt + dy], bf[step % (PFB + 1)][nt], acc[mt][nt]);
+        for (int nt = 0; nt < C::NT; ++nt) mma<T>(bf[step % (PFB + 1)][nt], af[dx & 1][mt + dy], acc[mt][nt]);   // D[cout][pixel]
       __builtin_amdgcn_sched_barrier(0);
     }
     // round l + 1 has landed once at most the pieces of the rounds after it are still in flight;
@@ -353,11 +358,13 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
   __syncthreads();
   STV_STAMP(2);
 
-  // ---- epilogue: accumulators -> LDS C tile (fp32) -> 16-byte vector stores ----
-  // A thread's vectors all sit in the same channel group (THREADS % VPR == 0): its bias slice and
-  // every mask / accumulate operand are requested up front, before the C tile is even written.
-  constexpr int EIT = C::BM * VPR / C::THREADS;
-  static_assert(C::BM * VPR % C::THREADS == 0 && C::THREADS % VPR == 0, "epilogue split");
+  // ---- epilogue, in registers ----------------------------------------------------------------
+  // A lane holds, per (row block, 32-channel block), 4 groups of 4 consecutive channels of ONE
+  // pixel.  fp32: each group is a 16-byte store as it is.  bf16: a group packs to 8 bytes;
+  // v_permlane32_swap trades groups with the partner lane (same pixel, other h) so that lanes
+  // 0-31 end up with channels 8j..8j+7 and lanes 32-63 with 8j+8..8j+15 of a group pair: two
+  // 16-byte stores per 32 channels, no LDS round trip and no barrier.  Only the K-split variant
+  // still meets in LDS (the second group's partial sums).
   const bool relu_out = (a.flags & STV_RELU_OUT) != 0;
   const bool do_mask = (a.flags & STV_MASK) != 0;
   const bool do_acc = (a.flags & STV_ACCUM) != 0;
@@ -366,103 +373,140 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
   const __amdgpu_buffer_rsrc_t rs_ref = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<void*>(a.ref), 0, do_mask ? out_bytes : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_old = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, do_acc ? out_bytes : 0, 0x00020000);
-  uint32_t o_off[EIT];
-  u32x4 refv[EIT], oldv[EIT];
-#pragma unroll
-  for (int it = 0; it < EIT; ++it) {
-    const int pix = (it * C::THREADS + tid) / VPR;
-    const int gy = y0 + (pix >> 5), gx = x0 + (pix & 31);
-    const bool ok = gy < a.H && gx < a.W && n < a.cout;
-    o_off[it] = ok ? (uint32_t)(((gy * a.W + gx) * a.cout + n) * (int)sizeof(T)) : kOob;
-    refv[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_ref, o_off[it], 0, 0);
-    oldv[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_old, o_off[it], 0, 0);
-  }
 
-  float* cs = reinterpret_cast<float*>(smem);
-  // mode 0: tile = accumulators; mode 1: accumulators += tile (over this lane's share of the tile)
-  auto c_tile = [&](auto mode) {
+  if (C::KS == 2) {               // the second K group hands its partial sums over through LDS
+    float* cs = reinterpret_cast<float*>(smem);
+    auto c_tile = [&](auto mode) {
 #pragma unroll
-    for (int mt = 0; mt < C::MT; ++mt)
+      for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < C::NT; ++nt)
+        for (int nt = 0; nt < C::NT; ++nt)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int row = (wm * C::MT + mt) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-          const int col = wn * (C::NT * 32) + nt * 32 + r;
-          if (decltype(mode)::value == 0) cs[row * C::CS + col] = acc[mt][nt][i];
-          else acc[mt][nt][i] += cs[row * C::CS + col];
-        }
-  };
-  using Put = std::integral_constant<int, 0>;
-  using Add = std::integral_constant<int, 1>;
-  if (C::KS == 2) {               // the second K group hands its partial sums over through the tile
-    if (grp == 1) c_tile(Put{});
+          for (int i = 0; i < 16; ++i) {
+            const int row = (wm * C::MT + mt) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            const int col = wn * (C::NT * 32) + nt * 32 + r;
+            if (decltype(mode)::value == 0) cs[row * C::CS + col] = acc[mt][nt][i];
+            else acc[mt][nt][i] += cs[row * C::CS + col];
+          }
+    };
+    if (grp == 1) c_tile(std::integral_constant<int, 0>{});
     __syncthreads();
-    if (grp == 0) c_tile(Add{});
-    __syncthreads();
+    if (grp == 0) c_tile(std::integral_constant<int, 1>{});
   }
-  if (grp == 0) c_tile(Put{});
-  __syncthreads();
   STV_STAMP(3);
 
+  if (grp == 0) {
+    // emit one map: `val(mt, nt, i)` yields the raw sum, `pix_ok` / `pix_off` place pixel (mt, r)
+    auto emit = [&](auto&& val, auto&& pix_off, const __amdgpu_buffer_rsrc_t& rs_out, int MTN, bool masked, bool accum) {
 #pragma unroll
-  for (int it = 0; it < EIT; ++it) {
-    const int pix = (it * C::THREADS + tid) / VPR;
-    float val[kVec];
+      for (int mt = 0; mt < C::MT; ++mt) {
+        if (mt >= MTN) continue;
+        const uint32_t poff = pix_off(mt);                  // byte offset of this lane's pixel, or kOob
 #pragma unroll
-    for (int q = 0; q < kVec / 4; ++q) {
-      const f32x4 t = *reinterpret_cast<const f32x4*>(cs + pix * C::CS + cv * kVec + q * 4);
+        for (int nt = 0; nt < C::NT; ++nt) {
+          const int nb = n0 + wn * (C::NT * 32) + nt * 32;   // first channel of the block
+          if constexpr (sizeof(T) == 4) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) val[q * 4 + e] = t[e] + bias_v[q][e];
-    }
-    if (relu_out) {
+            for (int j = 0; j < 4; ++j) {
+              const int nn = nb + 8 * j + 4 * h;
+              const uint32_t off = (poff != kOob && nn < a.cout) ? poff + (uint32_t)(nn * 4) : kOob;
+              float v[4];
 #pragma unroll
-      for (int e = 0; e < kVec; ++e) val[e] = fmaxf(val[e], 0.0f);
-    }
-    if (do_mask) {
-      float m[kVec];
-      unpack16<T>(refv[it], m);
+              for (int e = 0; e < 4; ++e) {
+                v[e] = val(mt, nt, 4 * j + e) + bias_v[nt][j][e];
+                if (relu_out) v[e] = fmaxf(v[e], 0.0f);
+              }
+              if (masked) {
+                const u32x4 m = __builtin_amdgcn_raw_buffer_load_b128(rs_ref, off, 0, 0);
 #pragma unroll
-      for (int e = 0; e < kVec; ++e) val[e] = (m[e] > 0.0f) ? val[e] : 0.0f;
-    }
-    if (do_acc) {
-      float old[kVec];
-      unpack16<T>(oldv[it], old);
+                for (int e = 0; e < 4; ++e) v[e] = (__uint_as_float(m[e]) > 0.0f) ? v[e] : 0.0f;
+              }
+              if (accum) {
+                const u32x4 o = __builtin_amdgcn_raw_buffer_load_b128(rs_old, off, 0, 0);
 #pragma unroll
-      for (int e = 0; e < kVec; ++e) val[e] += old[e];
-    }
-    __builtin_amdgcn_raw_buffer_store_b128(pack16<T>(val), rs_y, o_off[it], 0, 0);   // OOB lanes are dropped
-  }
-  // Fused MaxPool2d(2,2) (forward convs in front of a pool): the 2x2 windows of this tile are
-  // complete in the C tile (TH and the tile origin are even), max / bias / ReLU commute, so the
-  // pooled map costs four more LDS reads per output vector instead of a second pass over HBM.
-  if (a.pool != nullptr) {
-    const int Hp = a.H >> 1, Wp = a.W >> 1;
-    const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(a.pool, 0, Hp * Wp * a.cout * (int)sizeof(T), 0x00020000);
-    constexpr int PVEC = (C::BM / 4) * VPR;
+                for (int e = 0; e < 4; ++e) v[e] += __uint_as_float(o[e]);
+              }
+              const u32x4 out = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+              __builtin_amdgcn_raw_buffer_store_b128(out, rs_out, off, 0, 0);
+            }
+          } else {
+            uint32_t px[4], py[4];                            // group j packed: (x = channels 0,1; y = 2,3)
 #pragma unroll
-    for (int it = 0; it < (PVEC + C::THREADS - 1) / C::THREADS; ++it) {
-      const int idx = it * C::THREADS + tid;
-      const int q = idx / VPR;                          // pooled pixel of the tile: 16 per row
-      const int qy = q >> 4, qx = q & 15;
-      const int gyp = (y0 >> 1) + qy, gxp = (x0 >> 1) + qx;
-      const bool ok = idx < PVEC && gyp < Hp && gxp < Wp && n < a.cout;
-      float val[kVec];
+            for (int j = 0; j < 4; ++j) {
+              float v[4];
 #pragma unroll
-      for (int qq = 0; qq < kVec / 4; ++qq) {
-        const float* src = cs + ((2 * qy) * 32 + 2 * qx) * C::CS + cv * kVec + qq * 4;
-        const f32x4 t0 = *reinterpret_cast<const f32x4*>(src);
-        const f32x4 t1 = *reinterpret_cast<const f32x4*>(src + C::CS);
-        const f32x4 t2 = *reinterpret_cast<const f32x4*>(src + 32 * C::CS);
-        const f32x4 t3 = *reinterpret_cast<const f32x4*>(src + 33 * C::CS);
+              for (int e = 0; e < 4; ++e) {
+                v[e] = val(mt, nt, 4 * j + e) + bias_v[nt][j][e];
+                if (relu_out) v[e] = fmaxf(v[e], 0.0f);
+              }
+              if (accum) {        // exact: fp32 add before the one rounding, in the pre-swap layout
+                const int nn = nb + 8 * j + 4 * h;
+                const uint32_t off = (poff != kOob && nn < a.cout) ? poff + (uint32_t)(nn * 2) : kOob;
+                if (masked) {     // the mask applies to the new term only: it has to come first
+                  const auto m = __builtin_amdgcn_raw_buffer_load_b64(rs_ref, off, 0, 0);
+                  v[0] = ((int)(m[0] << 16) > 0) ? v[0] : 0.0f;
+                  v[1] = ((int)(m[0] & 0xFFFF0000u) > 0) ? v[1] : 0.0f;
+                  v[2] = ((int)(m[1] << 16) > 0) ? v[2] : 0.0f;
+                  v[3] = ((int)(m[1] & 0xFFFF0000u) > 0) ? v[3] : 0.0f;
+                }
+                const auto o = __builtin_amdgcn_raw_buffer_load_b64(rs_old, off, 0, 0);
+                v[0] += __uint_as_float(o[0] << 16);
+                v[1] += __uint_as_float(o[0] & 0xFFFF0000u);
+                v[2] += __uint_as_float(o[1] << 16);
+                v[3] += __uint_as_float(o[1] & 0xFFFF0000u);
+              }
+              px[j] = pack_bf16x2(v[0], v[1]);
+              py[j] = pack_bf16x2(v[2], v[3]);
+            }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float m = fmaxf(fmaxf(t0[e], t1[e]), fmaxf(t2[e], t3[e])) + bias_v[qq][e];
-          val[qq * 4 + e] = relu_out ? fmaxf(m, 0.0f) : m;
+            for (int jp = 0; jp < 4; jp += 2) {
+              // lanes 32-63 of the group-jp register <-> lanes 0-31 of the group-(jp+1) register
+              const auto sx = __builtin_amdgcn_permlane32_swap(px[jp], px[jp + 1], false, false);
+              const auto sy = __builtin_amdgcn_permlane32_swap(py[jp], py[jp + 1], false, false);
+              u32x4 out = {sx[0], sy[0], sx[1], sy[1]};
+              const int nn = nb + 8 * jp + 8 * h;             // lanes 0-31: 8jp..8jp+7, lanes 32-63: the next eight
+              const uint32_t off = (poff != kOob && nn < a.cout) ? poff + (uint32_t)(nn * 2) : kOob;
+              if (masked && !accum) {   // (ref > 0) on packed bf16: positive <=> signed 16-bit value > 0
+                typedef __attribute__((ext_vector_type(8))) short s16x8;
+                const s16x8 m = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_ref, off, 0, 0));
+                const s16x8 keep = (s16x8)(m > (s16x8)(short)0);          // 0xFFFF where ref > 0
+                out = __builtin_bit_cast(u32x4, __builtin_bit_cast(s16x8, out) & keep);
+              }
+              __builtin_amdgcn_raw_buffer_store_b128(out, rs_out, off, 0, 0);
+            }
+          }
         }
       }
-      const uint32_t off = ok ? (uint32_t)(((gyp * Wp + gxp) * a.cout + n) * (int)sizeof(T)) : kOob;
-      __builtin_amdgcn_raw_buffer_store_b128(pack16<T>(val), rs_p, off, 0, 0);
+    };
+    auto full_off = [&](int mt) -> uint32_t {
+      const int gy = y0 + wm * C::MT + mt, gx = x0 + r;
+      return (gy < a.H && gx < a.W) ? (uint32_t)(((gy * a.W + gx) * a.cout) * (int)sizeof(T)) : kOob;
+    };
+    emit([&](int mt, int nt, int i) { return acc[mt][nt][i]; }, full_off, rs_y, C::MT, do_mask, do_acc);
+
+    // Fused MaxPool2d(2,2) (forward convs in front of a pool): the vertical pair of a window is
+    // two accumulator sets of this wave (MT is even, tile origin even), the horizontal pair the
+    // neighbouring lane; max, bias and ReLU commute, so the pooled map is the same arithmetic on
+    // max'ed sums - no second pass over HBM.  Even lanes store pooled pixel r / 2.
+    if (a.pool != nullptr) {
+      static_assert(C::MT % 2 == 0, "a wave owns both rows of a pooling window");
+      const int Hp = a.H >> 1, Wp = a.W >> 1;
+      const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(a.pool, 0, Hp * Wp * a.cout * (int)sizeof(T), 0x00020000);
+      f32x16 pm[C::MT / 2][C::NT];
+#pragma unroll
+      for (int mp = 0; mp < C::MT / 2; ++mp)
+#pragma unroll
+        for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const float v = fmaxf(acc[2 * mp][nt][i], acc[2 * mp + 1][nt][i]);
+            pm[mp][nt][i] = fmaxf(v, __shfl_xor(v, 1, 64));
+          }
+      auto pool_off = [&](int mp) -> uint32_t {
+        const int gyp = ((y0 + wm * C::MT) >> 1) + mp, gxp = (x0 + r) >> 1;
+        return ((r & 1) == 0 && gyp < Hp && gxp < Wp) ? (uint32_t)(((gyp * Wp + gxp) * a.cout) * (int)sizeof(T)) : kOob;
+      };
+      emit([&](int mp, int nt, int i) { return pm[mp < C::MT / 2 ? mp : 0][nt][i]; }, pool_off, rs_p, C::MT / 2, false, false);
     }
   }
   STV_STAMP(4);

@@ -275,13 +275,21 @@ __global__ __launch_bounds__(256) void solve_kernel(CState* st, CWs w, int hist,
   }
   __threadfence_block();
   __syncthreads();
-  for (int i = tid >> 6; i < m; i += 4) {            // one table row per wave, lanes along the row
-    const size_t row = (size_t)((head + i) % S) * S;
-    for (int j = tid & 63; j < m; j += 64) {
+  {
+    // table fill: thread = (row parity, column); eight rows of loads in flight per thread - walking
+    // the rows one load at a time made this fill, not the recursion, the longest part of the kernel
+    const int j = tid & 127, i0 = tid >> 7;
+    if (j < m) {
       int col = head + j;
       if (col >= S) col -= S;
-      sSY[i * P + j] = w.SY[row + col];
-      sYY[i * P + j] = w.YY[row + col];
+#pragma unroll 8
+      for (int i = i0; i < m; i += 2) {
+        int rs = head + i;
+        if (rs >= S) rs -= S;
+        const size_t src = (size_t)rs * S + col;
+        sSY[i * P + j] = w.SY[src];
+        sYY[i * P + j] = w.YY[src];
+      }
     }
   }
   __syncthreads();
