@@ -99,7 +99,8 @@ struct Cfg {
   static constexpr int CS = BN + 4;                  // C-tile pitch in floats
   static constexpr int C_BYTES = BM * CS * 4;
   static constexpr int RING_BYTES = NBUF * KS * STAGE_BYTES;
-  static constexpr int LDS_BYTES = (RING_BYTES > C_BYTES) ? RING_BYTES : C_BYTES;
+  // the fp32 C tile only exists where two K groups merge their partial sums
+  static constexpr int LDS_BYTES = (KS == 1 || RING_BYTES > C_BYTES) ? RING_BYTES : C_BYTES;
   static_assert(NWAVES * KS == 4 || NWAVES * KS == 8, "4 or 8 waves per workgroup");
   static_assert(KS == 1 || KS == 2, "K split");
   static_assert(NBUF == 2 || NBUF == 3, "ring depth");
@@ -488,8 +489,7 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
     // two accumulator sets of this wave (MT is even, tile origin even), the horizontal pair the
     // neighbouring lane; max, bias and ReLU commute, so the pooled map is the same arithmetic on
     // max'ed sums - no second pass over HBM.  Even lanes store pooled pixel r / 2.
-    if (a.pool != nullptr) {
-      static_assert(C::MT % 2 == 0, "a wave owns both rows of a pooling window");
+    if constexpr (C::MT % 2 == 0) if (a.pool != nullptr) {     // (a wave must own both rows of a pooling window)
       const int Hp = a.H >> 1, Wp = a.W >> 1;
       const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(a.pool, 0, Hp * Wp * a.cout * (int)sizeof(T), 0x00020000);
       f32x16 pm[C::MT / 2][C::NT];
@@ -567,9 +567,10 @@ int launch_cfg(const ConvArgs& a, hipStream_t st) {
 
 // ---- tile choice --------------------------------------------------------------------------------
 // Configurations: 0 = 8x128, 1 = 8x64, 2 = 4x128, 3 = 4x64 (TH x BN), 4 = 4x64 with K split over two
-// wave groups, 5 = 8x64 on a two-deep LDS ring (two workgroups per CU).  -1 = the shape is outside the matrix-core tiling (direct fallback).
-constexpr int kNumCfg = 6;
-const int kCfgTH[kNumCfg] = {8, 8, 4, 4, 4, 8}, kCfgBN[kNumCfg] = {128, 64, 128, 64, 64, 64};
+// wave groups, 5 = 8x64 and 6 = 4x64 on a two-deep LDS ring (two / three workgroups per CU),
+// 7 = 2x64 with the K split (the 32x32-pixel layers: four times the workgroups of 4x64 x 2).  -1 = the shape is outside the matrix-core tiling (direct fallback).
+constexpr int kNumCfg = 8;
+const int kCfgTH[kNumCfg] = {8, 8, 4, 4, 4, 8, 4, 2}, kCfgBN[kNumCfg] = {128, 64, 128, 64, 64, 64, 64, 64};
 
 bool cfg_valid(int cfg, int cout) { return cfg >= 0 && cfg < kNumCfg && !(cout <= 64 && kCfgBN[cfg] == 128); }
 
@@ -624,13 +625,16 @@ int launch_mfma(const ConvArgs& a, int cfg, hipStream_t st) {
     case 2: return launch_cfg<Cfg<T, 4, 128, 1, 4, TAPS>>(a, st);
     case 4: return launch_cfg<Cfg<T, 4, 64, 2, 2, TAPS, 2>>(a, st);   // small layers: K split over two wave groups
     case 5: return launch_cfg<Cfg<T, 8, 64, 4, 2, TAPS, 1, 2>>(a, st);
+    case 6: return launch_cfg<Cfg<T, 4, 64, 2, 2, TAPS, 1, 2>>(a, st);
+    case 7: return launch_cfg<Cfg<T, 2, 64, 2, 2, TAPS, 2>>(a, st);
     default: return launch_cfg<Cfg<T, 4, 64, 2, 2, TAPS>>(a, st);
   }
 }
 
 template <typename T, int TAPS>
 int launch_typed(const ConvArgs& a, hipStream_t st) {
-  const int cfg = choose_cfg(a.H, a.W, a.cin, a.cout, (int)sizeof(T), TAPS);
+  int cfg = choose_cfg(a.H, a.W, a.cin, a.cout, (int)sizeof(T), TAPS);
+  if (cfg == 7 && a.pool != nullptr) cfg = 4;      // a 2-row tile holds one row per wave: no pooling window
   if (cfg < 0) {
     const size_t total = (size_t)a.H * a.W * a.cout;
     hipLaunchKernelGGL((conv_direct_kernel<T, TAPS>), dim3((unsigned)((total + 255) / 256)),
@@ -668,7 +672,9 @@ int tune_typed(int H, int W, int cin, int cout, int taps, hipStream_t st) {
   int best = base;
   float t_best = 3.4e38f, t_base = 3.4e38f;
   int rc = STV_OK;
-  for (int cfg = 0; cfg < kNumCfg && rc == STV_OK; ++cfg) {
+  int ncfg = kNumCfg;
+  if (const char* lim = getenv("STV_CONV_TUNE_CFGS")) ncfg = atoi(lim) < kNumCfg ? atoi(lim) : kNumCfg;   // A/B aid
+  for (int cfg = 0; cfg < ncfg && rc == STV_OK; ++cfg) {
     if (!cfg_valid(cfg, cout)) continue;
     constexpr int kWarm = 2, kReps = 6;
     for (int i = 0; i < kWarm && rc == STV_OK; ++i)

@@ -39,7 +39,7 @@ int main(int argc, char** argv) {
   float ms = 0;
   hipEventElapsedTime(&ms, e0, e1);
   const int cfg = stv_conv_config(H, W, cin, cout, 9, STV_BF16);
-  static const int th[6] = {8, 8, 4, 4, 4, 8}, bn[6] = {128, 64, 128, 64, 64, 64};
+  static const int th[8] = {8, 8, 4, 4, 4, 8, 4, 2}, bn[8] = {128, 64, 128, 64, 64, 64, 64, 64};
   const int nwg = ((W + 31) / 32) * ((H + th[cfg] - 1) / th[cfg]) * ((cout + bn[cfg] - 1) / bn[cfg]);
   std::vector<unsigned long long> st_h((size_t)nwg * 8);
   hipMemcpyFromSymbol(st_h.data(), HIP_SYMBOL(g_stv_stamps), st_h.size() * 8);
