@@ -196,6 +196,12 @@ enum {
   STV_OP_GRAM_FINISH, STV_OP_CONTENT_LOSS, STV_OP_CONTENT_GRAD, STV_OP_LOSS_COMBINE,
   STV_OP_MEMSET
 };
+/* Scheduling hints in stv_op_t.flags (masked off before the kernel sees them):
+ * an op with STV_LANE_SIDE may run concurrently with the ops after it: it reads only
+ * what earlier ops produced, and what it writes is first read by an op flagged
+ * STV_LANE_JOIN (or after the program).  The executor runs such ops on a second
+ * stream forked from / joined to the caller's stream with events. */
+enum { STV_LANE_SIDE = 1 << 29, STV_LANE_JOIN = 1 << 30 };
 /* Operands follow the direct entry points' argument order (inputs p0.., outputs q0..).
  * CONV_FIRST_FWD takes the optional stv_conv_first_pack buffer in p3, CONV_FIRST_DGRAD in p2;
  * CONV with q1 set runs stv_conv_igemm_pool (q1 = pooled output). */

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libstv_hip.so")
 
 STV_F32, STV_BF16 = 0, 1
 RELU_IN, RELU_OUT, MASK, ACCUM, W_BLOCKED = 1, 2, 4, 8, 16
+LANE_SIDE, LANE_JOIN = 1 << 29, 1 << 30          # scheduling hints of the command-buffer executor
 
 (OP_CONV_FIRST_FWD, OP_CONV_FIRST_DGRAD, OP_CONV, OP_POOL_FWD, OP_POOL_BWD, OP_RELU_FWD,
  OP_RELU_BWD, OP_GRAM_PARTIAL, OP_GRAM_FINISH, OP_CONTENT_LOSS, OP_CONTENT_GRAD,

@@ -17,7 +17,7 @@ from urllib.parse import urlparse
 import torch
 from torch import nn
 
-from . import ops, plan, synthetic
+from . import _lib, ops, plan, synthetic
 from .constants import GRAM_MATRIX_CLAMP_MAX
 from .logging_utils import logger
 
@@ -216,9 +216,10 @@ class _Engine:
     # -- op list pieces -------------------------------------------------------
     def _tap_loss_ops(self, tap, *, style_coef: float, coef_dev: torch.Tensor | None, with_seed: bool) -> list:
         """Loss-side ops of one tap.  They are spliced in right after the op that produces the tapped
-        activation, while it is still L2 / Infinity-Cache resident.  (Running them on a second
-        stream beside the next convolution was measured and lost 2-5 %: the conv grids that leave
-        CUs idle are too short for the extra fork/join to pay.)"""
+        activation, while it is still L2 / Infinity-Cache resident.  STV_SIDE_LANE=1 flags them for
+        the executor's second stream (fork after the tapped conv, join at the score combine); measured
+        twice on MI355X, it loses 2-5 % inside the captured graph (6 forks + 1 join cost more than the
+        ~100 us of overlap they buy), so it stays off by default."""
         s = self.sched
         if tap.kind == "style":
             cd = coef_dev[tap.order:] if coef_dev is not None else None
@@ -227,6 +228,11 @@ class _Engine:
         else:
             ops_ = [s._op(op=plan.OP_CONTENT_LOSS, p0=tap.buf.act, p1=tap.target,
                           q0=self.parts[tap.parts_off:], n=tap.buf.act.numel())]
+        if os.environ.get("STV_SIDE_LANE", "0") == "1":
+            # loss-side chains only read the tapped activation and write buffers that nothing reads
+            # before the score combine: they may overlap the main chain (executor's second stream)
+            for o in ops_:
+                o.flags |= _lib.LANE_SIDE
         return ops_
 
     def _forward_with_losses(self, x: torch.Tensor, *, style_coef: float, with_seed: bool) -> list:
@@ -246,6 +252,7 @@ class _Engine:
         op = self.sched._op(op=plan.OP_LOSS_COMBINE, p0=self.parts, p1=self.table, p2=self.scale,
                             q0=self.losses, q1=self.scores, cin=self.n_style + self.n_content,
                             f0=style_w, f1=content_w)
+        op.flags |= _lib.LANE_JOIN          # first reader of what the loss-side ops wrote
         return op
 
     def _program(self, key: tuple, builder) -> plan.Program:

@@ -11,11 +11,17 @@ struct stv_program {
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
   hipStream_t captured_on = nullptr;
+  // side lane (ops flagged STV_LANE_SIDE): a second stream forked from / joined to the caller's
+  // stream with events, so that small latency-bound chains overlap the main chain
+  hipStream_t side = nullptr;
+  std::vector<hipEvent_t> events;
 };
 
 namespace {
 
-int run_op(const stv_op_t& o, void* st) {
+int run_op(const stv_op_t& op, void* st) {
+  stv_op_t o = op;
+  o.flags &= ~(STV_LANE_SIDE | STV_LANE_JOIN);      // scheduling hints, not kernel flags
   switch (o.op) {
     case STV_OP_CONV_FIRST_FWD:   // p3 (optional): weights packed by stv_conv_first_pack
       if (o.p3)
@@ -70,12 +76,65 @@ int run_op(const stv_op_t& o, void* st) {
   }
 }
 
-int run_all(const stv_program* p, void* st) {
-  for (const stv_op_t& o : p->ops) {
-    const int rc = run_op(o, st);
-    if (rc != STV_OK) return rc;
+hipEvent_t next_event(stv_program* p, size_t& used) {
+  if (used == p->events.size()) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    p->events.push_back(e);
   }
-  return STV_OK;
+  return p->events[used++];
+}
+
+// Ops run in program order on `st`, except ops flagged STV_LANE_SIDE: those go to the program's
+// second stream, which waits for everything enqueued on `st` before the op (fork) and is waited for
+// by the first later op flagged STV_LANE_JOIN, or by the end of the program (join).  The same
+// calls build the dependency edges when `st` is being captured into a graph.
+int run_all(stv_program* p, void* st, bool lanes) {
+  hipStream_t main_s = static_cast<hipStream_t>(st);
+  bool any_side = false;
+  if (lanes)
+    for (const stv_op_t& o : p->ops) any_side |= (o.flags & STV_LANE_SIDE) != 0;
+  if (!any_side) {
+    for (const stv_op_t& o : p->ops) {
+      const int rc = run_op(o, st);
+      if (rc != STV_OK) return rc;
+    }
+    return STV_OK;
+  }
+  if (!p->side && hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess) return STV_ERR_ALLOC;
+  size_t used = 0;
+  bool side_busy = false;        // side lane holds work the main lane has not waited for
+  bool main_moved = true;        // main lane enqueued work since the side lane last synchronised with it
+  auto join = [&]() -> int {
+    if (!side_busy) return STV_OK;
+    hipEvent_t e = next_event(p, used);
+    if (!e || hipEventRecord(e, p->side) != hipSuccess || hipStreamWaitEvent(main_s, e, 0) != hipSuccess)
+      return STV_ERR_LAUNCH;
+    side_busy = false;
+    return STV_OK;
+  };
+  for (const stv_op_t& o : p->ops) {
+    int rc = STV_OK;
+    if (o.flags & STV_LANE_SIDE) {
+      if (main_moved) {
+        hipEvent_t e = next_event(p, used);
+        if (!e || hipEventRecord(e, main_s) != hipSuccess || hipStreamWaitEvent(p->side, e, 0) != hipSuccess)
+          return STV_ERR_LAUNCH;
+        main_moved = false;
+      }
+      rc = run_op(o, p->side);
+      side_busy = true;
+    } else {
+      if (o.flags & STV_LANE_JOIN) rc = join();
+      if (rc == STV_OK) rc = run_op(o, st);
+      main_moved = true;
+    }
+    if (rc != STV_OK) {
+      (void)join();              // never leave a captured side stream dangling
+      return rc;
+    }
+  }
+  return join();
 }
 
 }  // namespace
@@ -95,7 +154,7 @@ extern "C" int stv_program_run(stv_program* prog, int use_graph, void* stream) {
   if (!prog) return STV_ERR_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   // The legacy default stream cannot be captured: run eagerly there.
-  if (!use_graph || st == nullptr) return run_all(prog, stream);
+  if (!use_graph || st == nullptr) return run_all(prog, stream, true);
   if (prog->exec && prog->captured_on != st) {
     (void)hipGraphExecDestroy(prog->exec);
     (void)hipGraphDestroy(prog->graph);
@@ -104,13 +163,13 @@ extern "C" int stv_program_run(stv_program* prog, int use_graph, void* stream) {
   }
   if (!prog->exec) {
     // Eager warm-up first: one-time hipFuncSetAttribute calls must not land inside a capture.
-    int rc = run_all(prog, stream);
+    int rc = run_all(prog, stream, true);
     if (rc != STV_OK) return rc;
     if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
       (void)hipGetLastError();  // do not leave a sticky error behind for the caller's runtime
       return STV_ERR_GRAPH;
     }
-    rc = run_all(prog, stream);
+    rc = run_all(prog, stream, true);
     hipGraph_t g = nullptr;
     if (hipStreamEndCapture(st, &g) != hipSuccess || rc != STV_OK) {
       if (g) (void)hipGraphDestroy(g);
@@ -162,5 +221,7 @@ extern "C" void stv_program_destroy(stv_program* prog) {
   if (!prog) return;
   if (prog->exec) (void)hipGraphExecDestroy(prog->exec);
   if (prog->graph) (void)hipGraphDestroy(prog->graph);
+  for (hipEvent_t e : prog->events) (void)hipEventDestroy(e);
+  if (prog->side) (void)hipStreamDestroy(prog->side);
   delete prog;
 }
