@@ -10,7 +10,7 @@ import os
 from ctypes import c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstv_hip.so")
+LIB_PATH = os.environ.get("STV_LIB_PATH") or os.path.join(_HERE, "libstv_hip.so")   # override: diagnostic builds
 
 STV_F32, STV_BF16 = 0, 1
 RELU_IN, RELU_OUT, MASK, ACCUM, W_BLOCKED = 1, 2, 4, 8, 16

@@ -12,6 +12,10 @@
 
 #include "stv_common.h"
 
+#ifndef STV_FIRST_DIAG   // diagnostic builds knock out phases of the matrix-core forward kernel (timing only)
+#define STV_FIRST_DIAG 0
+#endif
+
 namespace {
 
 constexpr int kMaxCin = 4;
@@ -253,12 +257,10 @@ __global__ __launch_bounds__(256) void conv_first_fwd_mfma(const float* __restri
                                                            const float* __restrict__ bias,
                                                            bf16_t* __restrict__ y, int H, int W) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int CS = 64 + 4;                                 // C-tile pitch (floats)
   // [c][row][col]; every pixel value is stored already split: bf16 hi in the upper, bf16 lo (the
   // remainder) in the lower half of the word - split once here, not once per tap it is read for.
   // Last word = 0.
   __shared__ __attribute__((aligned(16))) uint32_t xs[3 * MF_PLANE + 4];
-  __shared__ __attribute__((aligned(16))) float cs_all[4 * MF_TW * CS];   // one 32-pixel row block per wave at a time
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int tiles_x = (W + MF_TW - 1) / MF_TW;
@@ -302,11 +304,15 @@ __global__ __launch_bounds__(256) void conv_first_fwd_mfma(const float* __restri
       const int tap = k / 3, c = k - tap * 3;
       koff[ks][e] = (k < 27) ? c * MF_PLANE + (tap / 3) * MF_IW + (tap % 3) : -1;
     }
-  const int cv = lane & 7;                                  // 8 vectors of 8 channels per pixel
-  float bv[8];
+  // accumulator layout (weights are the MFMA row operand): lane = pixel r, registers = channels
+  // nt * 32 + 8j + 4h + e of that pixel
+  f32x4 bv[2][4];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) bv[e] = bias ? bias[cv * 8 + e] : 0.0f;
-  float* cs = cs_all + wave * (MF_TW * CS);
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bv[nt][j][e] = bias ? bias[nt * 32 + 8 * j + 4 * h + e] : 0.0f;
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
   const int x0 = (t % tiles_x) * MF_TW, y0 = (t / tiles_x) * MF_TH;
   __syncthreads();                       // every wave is done gathering from the previous tile
@@ -316,7 +322,7 @@ __global__ __launch_bounds__(256) void conv_first_fwd_mfma(const float* __restri
       const bf16_t hi = f32_to_bf16(pre[k]);
       xs[k * 256 + tid] = ((uint32_t)hi << 16) | (uint32_t)f32_to_bf16(pre[k] - bf16_to_f32(hi));
     }
-  if (t + (int)gridDim.x < ntiles) request(t + gridDim.x);
+  if (t + (int)gridDim.x < ntiles && !(STV_FIRST_DIAG & 4)) request(t + gridDim.x);
   __syncthreads();
   f32x16 acc[2][2];
 #pragma unroll
@@ -327,6 +333,7 @@ __global__ __launch_bounds__(256) void conv_first_fwd_mfma(const float* __restri
       for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.0f;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
+    if (STV_FIRST_DIAG & 1) break;          // timing only: no gathers, no MFMAs
     const int base = (wave * 2 + mt) * MF_IW + r;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -346,34 +353,35 @@ __global__ __launch_bounds__(256) void conv_first_fwd_mfma(const float* __restri
       const bf16x8v a_lo = __builtin_bit_cast(bf16x8v, (u32x4){lo4[0], lo4[1], lo4[2], lo4[3]});
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, bw[0][ks][nt], acc[mt][nt], 0, 0, 0);
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bw[1][ks][nt], acc[mt][nt], 0, 0, 0);
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bw[0][ks][nt], acc[mt][nt], 0, 0, 0);
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[0][ks][nt], a_lo, acc[mt][nt], 0, 0, 0);
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[1][ks][nt], a_hi, acc[mt][nt], 0, 0, 0);
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[0][ks][nt], a_hi, acc[mt][nt], 0, 0, 0);
       }
     }
   }
-  // accumulators -> this wave's strip of the C tile (one 32-pixel row at a time: LDS stays small
-  // enough for four workgroups per CU, whose load / compute / store phases then overlap), then
-  // 16-byte NHWC stores.  A wave's LDS operations are in order: no barrier between write and read.
+  // epilogue in registers: bias, pack groups of 4 channels, trade groups with the partner
+  // half-wave (v_permlane32_swap) so that every lane stores 16 contiguous bytes - no LDS transpose
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
+    const int gy = y0 + wave * 2 + mt, gx = x0 + r;
+    const bool ok = gy < H && gx < W;
+    bf16_t* dst = y + ((size_t)gy * W + gx) * 64;
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < 2; ++nt) {
+      uint32_t px[4], py[4];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) cs[((i & 3) + 8 * (i >> 2) + 4 * h) * CS + nt * 32 + r] = acc[mt][nt][i];
-    const int gy = y0 + wave * 2 + mt;
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int px = it * 8 + (lane >> 3);
-      const int gx = x0 + px;
-      float val[8];
-#pragma unroll
-      for (int qq = 0; qq < 2; ++qq) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(cs + px * CS + cv * 8 + qq * 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) val[qq * 4 + e] = t[e] + bv[qq * 4 + e];
+      for (int j = 0; j < 4; ++j) {
+        px[j] = pack_bf16x2(acc[mt][nt][4 * j] + bv[nt][j][0], acc[mt][nt][4 * j + 1] + bv[nt][j][1]);
+        py[j] = pack_bf16x2(acc[mt][nt][4 * j + 2] + bv[nt][j][2], acc[mt][nt][4 * j + 3] + bv[nt][j][3]);
       }
-      if (gy < H && gx < W) *reinterpret_cast<u32x4*>(y + ((size_t)gy * W + gx) * 64 + cv * 8) = pack16<bf16_t>(val);
+#pragma unroll
+      for (int jp = 0; jp < 4; jp += 2) {
+        const auto sx = __builtin_amdgcn_permlane32_swap(px[jp], px[jp + 1], false, false);
+        const auto sy = __builtin_amdgcn_permlane32_swap(py[jp], py[jp + 1], false, false);
+        const u32x4 out = {sx[0], sy[0], sx[1], sy[1]};     // lanes 0-31: channels 8jp..8jp+7, lanes 32-63: the next eight
+        if (ok && !(STV_FIRST_DIAG & 2)) *reinterpret_cast<u32x4*>(dst + nt * 32 + 8 * jp + 8 * h) = out;
+        if ((STV_FIRST_DIAG & 2) && out[0] == 0x12345678u) dst[0] = 1;   // keep the work alive
+      }
     }
   }
   }   // tiles
@@ -540,7 +548,8 @@ int fwd_typed(const float* x, const float* wf, const float* packed, const float*
               int cin, int cout, hipStream_t st) {
   if (cin == 3 && cout == 64 && packed && std::is_same<T, bf16_t>::value && !getenv("STV_FIRST_VALU")) {
     const int tiles = ceil_div(W, MF_TW) * ceil_div(H, MF_TH);
-    const int grid = tiles < 4 * 256 ? tiles : 4 * 256;       // four resident workgroups per CU walk the tiles
+    static const int wg_per_cu = getenv("STV_FIRST_WGS") ? atoi(getenv("STV_FIRST_WGS")) : 4;
+    const int grid = tiles < wg_per_cu * 256 ? tiles : wg_per_cu * 256;   // resident workgroups walk the tiles
     hipLaunchKernelGGL(conv_first_fwd_mfma, dim3(grid), dim3(256), 0, st, x,
                        reinterpret_cast<const uint32_t*>(packed + 2 * 1728), bias, static_cast<bf16_t*>(y), H, W);
     STV_CHECK_LAUNCH();
