@@ -110,6 +110,19 @@ int stv_conv_igemm(const void* x, const void* w, const float* bias, const void* 
 int stv_conv_igemm_pool(const void* x, const void* w, const float* bias, void* y, void* y_pool,
                         int H, int W, int cin, int cout, int flags, int dtype, void* stream);
 
+/* Two-term gradient in one launch:
+ *   y = [accumulate onto y +] mask(ref > 0) * conv3x3(x, w)  +  x2 . w2^T
+ * x2 is NHWC [H][W][cin2], w2 plain [cout][cin2].  This is the backward of a layer whose
+ * output feeds both the next conv (first term: that conv's dgrad, masked by this layer's
+ * ReLU) and a Gram loss tap (second term: dF = F.S, `core_model.py:56-63` backward) - the
+ * second term no longer needs its own launch nor a read-modify-write of y.
+ * flags: MASK (applies to the first term only), ACCUM, W_BLOCKED (for w).  Matrix-core
+ * shapes only (stv_conv_config(H,W,cin,cout,9,dtype) >= 0 and cin2 a multiple of the K
+ * stage), else STV_ERR_ARG and the caller issues the two launches. */
+int stv_conv_igemm_dual(const void* x, const void* w, const void* x2, const void* w2, const void* ref,
+                        void* y, int H, int W, int cin, int cin2, int cout, int flags, int dtype,
+                        void* stream);
+
 /* Which tile the dispatcher picks for a shape: -1 = scalar fallback (channel counts not a
  * multiple of the MFMA K-slice), else 0..3 = {8x128, 8x64, 4x128, 4x64} (rows x couts) and
  * 4 = 4x64 with K split over two wave groups, 5 = 8x64 and 6 = 4x64 with a two-deep LDS ring,
@@ -204,7 +217,8 @@ enum {
 enum { STV_LANE_SIDE = 1 << 29, STV_LANE_JOIN = 1 << 30 };
 /* Operands follow the direct entry points' argument order (inputs p0.., outputs q0..).
  * CONV_FIRST_FWD takes the optional stv_conv_first_pack buffer in p3, CONV_FIRST_DGRAD in p2;
- * CONV with q1 set runs stv_conv_igemm_pool (q1 = pooled output). */
+ * CONV with q1 set runs stv_conv_igemm_pool (q1 = pooled output); CONV with q2/q3 set runs
+ * stv_conv_igemm_dual (q2 = x2, q3 = w2, n = cin2: inputs, despite the slot names). */
 typedef struct {
   int32_t op, dtype, flags, taps;
   int32_t H, W, cin, cout;

@@ -53,6 +53,8 @@ SIGNATURES = {
     "stv_conv_first_dgrad_packed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "stv_conv_igemm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "stv_conv_igemm_pool": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "stv_conv_igemm_dual": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                    c_int, c_int, c_int, c_void_p]),
     "stv_conv_tune": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "stv_conv_config": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "stv_maxpool_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -117,6 +117,11 @@ struct ConvArgs {
   void* y;
   int H, W, cin, cout, flags;
   void* pool;   // optional second output: MaxPool2d(2,2) of y, [H/2][W/2][cout]
+  // optional fused 1x1 term: y = epilogue(mask(ref) * conv3x3(x, w) + x2 . w2^T), x2 [H][W][cin2],
+  // w2 [cout][cin2] plain rows (the Gram backward product riding in the dgrad that shares its output)
+  const void* x2;
+  const void* w2;
+  int cin2;
 };
 
 template <typename T> struct Frag;
@@ -153,60 +158,40 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// One pass of the implicit GEMM over a whole K range: streams `ph` (input tensor, weight tensor,
+// their K extent) through the LDS ring and accumulates into `acc`.  The kernel runs it once for
+// a plain convolution and a second time - 1x1 geometry, other tensors, same accumulators - for
+// the fused Gram-backward term.
+template <typename T>
+struct Phase {
+  const T* x;
+  const T* w;
+  int cin;
+  bool w_blocked;
+  uint32_t relu_floor;
+};
+struct Geom {
+  int H, W, cout, x0, y0, n0;
+  int lane, wave, grp, wm, wn, r, h;
+};
+
 template <typename C>
-__global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
-#if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (LDS address-space casts are device-only)
+__device__ __forceinline__ void conv_mainloop(const Phase<typename C::Elem>& ph, const Geom& gm, char* smem,
+                                              f32x16 (&acc)[C::MT][C::NT]) {
   using T = typename C::Elem;
   using FragT = typename Frag<T>::type;
   using lds_ptr = __attribute__((address_space(3))) void*;
   constexpr int kVec = elem_traits<T>::kVec;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave_wg = __builtin_amdgcn_readfirstlane(tid >> 6) & (C::NWAVES * C::KS - 1);   // scalar
-  const int grp = wave_wg / C::NWAVES;               // K group
-  const int wave = wave_wg % C::NWAVES;              // wave within the group
-  const int wm = wave / C::WN, wn = wave % C::WN;
-  const int r = lane & 31, h = lane >> 5;
-
-  const int tiles_x = (a.W + C::TW - 1) / C::TW;
-  const int tile_x = blockIdx.x % tiles_x;
-  const int tile_y = blockIdx.x / tiles_x;
-  const int x0 = tile_x * C::TW, y0 = tile_y * C::TH;
-  const int n0 = blockIdx.y * C::BN;
-
-  const T* __restrict__ xin = static_cast<const T*>(a.x);
-  const T* __restrict__ wgt = static_cast<const T*>(a.w);
-  const bool w_blocked = (a.flags & STV_W_BLOCKED) != 0;
-  const int nchunks = a.cin / C::CK;
-  // ReLU-on-load floor: integer max with 0 clears negative elements, with INT_MIN it is the identity
-  const uint32_t relu_floor = (a.flags & STV_RELU_IN) ? 0u : (sizeof(T) == 2 ? 0x80008000u : 0x80000000u);
-  STV_STAMP(0);
-  // Accumulator layout (MFMA roles: rows = output channels, columns = pixels): this lane owns
-  // pixel r of its wave's row blocks and, per 32-channel block, channels 8j + 4h + e (j, e < 4).
-  // Its bias values are requested first: a global round trip is ~2 us on a busy chip.
-  const int wm_ = (wave / C::WN), wn_ = (wave % C::WN);
-  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.bias), 0, a.bias != nullptr ? a.cout * 4 : 0, 0x00020000);
-  f32x4 bias_v[C::NT][4];           // channels past cout (and a null bias) read as zero
-#pragma unroll
-  for (int nt = 0; nt < C::NT; ++nt)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int nn = n0 + wn_ * (C::NT * 32) + nt * 32 + 8 * j + 4 * (lane >> 5);
-      const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (uint32_t)(nn * 4), 0, 0);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) bias_v[nt][j][e] = __uint_as_float(t[e]);
-    }
-
+  const int lane = gm.lane, wave = gm.wave, grp = gm.grp, wm = gm.wm, wn = gm.wn, r = gm.r, h = gm.h;
+  const int x0 = gm.x0, y0 = gm.y0, n0 = gm.n0;
+  const int nchunks = ph.cin / C::CK;
   // ---- DMA pieces of this wave: per-lane source byte offsets (out of range -> zero fill) ----
   constexpr uint32_t kOob = 0x80000000u;   // >= num_records for every tensor this kernel accepts
-  const int x_bytes = a.H * a.W * a.cin * (int)sizeof(T);
-  const int w_bytes = C::TAPS * a.cout * a.cin * (int)sizeof(T);
+  const int x_bytes = gm.H * gm.W * ph.cin * (int)sizeof(T);
+  const int w_bytes = C::TAPS * gm.cout * ph.cin * (int)sizeof(T);
   // bytes from one K-stage to the next: 32 along a pixel's (or plain weight row's) channels,
   // a whole [cout][CK] slab in the K-blocked weight layout
-  const int w_stride = w_blocked ? a.cout * C::KB : C::KB;
+  const int w_stride = ph.w_blocked ? gm.cout * C::KB : C::KB;
   // piece j of this wave is piece j * NWAVES + wave of the stage: input pieces first, then weights
   auto piece_id = [&](int j) { return j * C::NWAVES + wave; };                  // wave-uniform
   uint32_t p_off[C::PPW];
@@ -219,16 +204,16 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
       const int half = (v & 1) ^ ((pix >> 3) & 1);                 // swizzle on the source side
       const int py = pix / C::IN_W, px = pix - py * C::IN_W;
       const int gy = y0 + py - C::HALO, gx = x0 + px - C::HALO;
-      const bool ok = pix < C::IN_PIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-      p_off[j] = ok ? (uint32_t)(((gy * a.W + gx) * a.cin + half * kVec) * (int)sizeof(T)) : kOob;
+      const bool ok = pix < C::IN_PIX && gy >= 0 && gy < gm.H && gx >= 0 && gx < gm.W;
+      p_off[j] = ok ? (uint32_t)(((gy * gm.W + gx) * ph.cin + half * kVec) * (int)sizeof(T)) : kOob;
     } else {
       const int v = (g - C::IN_PIECES) * 64 + lane;
       const int row = v >> 1;
       const int half = (v & 1) ^ ((row >> 3) & 1);
       const int tap = row / C::BN, nn = row - tap * C::BN;
-      const bool ok = row < C::W_ROWS && (n0 + nn) < a.cout;
-      const int elem = w_blocked ? ((tap * nchunks * a.cout + n0 + nn) * C::CK + half * kVec)
-                                 : ((tap * a.cout + n0 + nn) * a.cin + half * kVec);
+      const bool ok = row < C::W_ROWS && (n0 + nn) < gm.cout;
+      const int elem = ph.w_blocked ? ((tap * nchunks * gm.cout + n0 + nn) * C::CK + half * kVec)
+                                 : ((tap * gm.cout + n0 + nn) * ph.cin + half * kVec);
       p_off[j] = ok ? (uint32_t)(elem * (int)sizeof(T)) : kOob;
     }
   }
@@ -243,18 +228,10 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
     const bool in = g < C::IN_PIECES;
     const bool live = g < C::PIECES && stage < nchunks && !(STV_DIAG & 1);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<T*>(in ? xin : wgt), 0, live ? (in ? x_bytes : w_bytes) : 0, 0x00020000);
+        const_cast<T*>(in ? ph.x : ph.w), 0, live ? (in ? x_bytes : w_bytes) : 0, 0x00020000);
     char* dst = buf + (g < C::PIECES ? g * 1024 : C::SPARE_OFF);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)dst, 16, p_off[j], stage * (in ? C::KB : w_stride), 0, 0);
   };
-
-  f32x16 acc[C::MT][C::NT];
-#pragma unroll
-  for (int mt = 0; mt < C::MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < C::NT; ++nt)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.0f;
 
   // lane-constant LDS byte offsets of this lane's fragments inside a stage buffer.  A: one per
   // (horizontal tap, halo row) - the swizzle bit depends on the pixel index; B: the row index is
@@ -283,7 +260,7 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
     FragT af[2][C::AROWS];
     FragT bf[PFB + 1][C::NT];
     auto load_a = [&](int dx, int j, int set) {
-      af[set][j] = relu_frag(*reinterpret_cast<const FragT*>(cur + a_addr[dx][j]), relu_floor);
+      af[set][j] = relu_frag(*reinterpret_cast<const FragT*>(cur + a_addr[dx][j]), ph.relu_floor);
     };
     auto load_b = [&](int step) {
       const int tap = (step % C::ND) * C::ND + step / C::ND;     // dy * 3 + dx
@@ -335,7 +312,6 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
   }
   wait_vmcnt<(C::NBUF - 2) * C::PPW>();
   __builtin_amdgcn_s_barrier();
-  STV_STAMP(1);
 
   int c = 0;
   if (C::NBUF == 3) {
@@ -357,7 +333,109 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
   // C tile takes over the same LDS
   wait_vmcnt<0>();
   __syncthreads();
+
+}
+
+template <typename C>
+__global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (LDS address-space casts are device-only)
+  using T = typename C::Elem;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave_wg = __builtin_amdgcn_readfirstlane(tid >> 6) & (C::NWAVES * C::KS - 1);   // scalar
+  const int grp = wave_wg / C::NWAVES;               // K group
+  const int wave = wave_wg % C::NWAVES;              // wave within the group
+  const int wm = wave / C::WN, wn = wave % C::WN;
+  const int r = lane & 31, h = lane >> 5;
+
+  const int tiles_x = (a.W + C::TW - 1) / C::TW;
+  const int tile_x = blockIdx.x % tiles_x;
+  const int tile_y = blockIdx.x / tiles_x;
+  const int x0 = tile_x * C::TW, y0 = tile_y * C::TH;
+  const int n0 = blockIdx.y * C::BN;
+
+  const T* __restrict__ xin = static_cast<const T*>(a.x);
+  const T* __restrict__ wgt = static_cast<const T*>(a.w);
+  const bool w_blocked = (a.flags & STV_W_BLOCKED) != 0;
+  const int nchunks = a.cin / C::CK;
+  // ReLU-on-load floor: integer max with 0 clears negative elements, with INT_MIN it is the identity
+  const uint32_t relu_floor = (a.flags & STV_RELU_IN) ? 0u : (sizeof(T) == 2 ? 0x80008000u : 0x80000000u);
+  STV_STAMP(0);
+  // Accumulator layout (MFMA roles: rows = output channels, columns = pixels): this lane owns
+  // pixel r of its wave's row blocks and, per 32-channel block, channels 8j + 4h + e (j, e < 4).
+  // Its bias values are requested first: a global round trip is ~2 us on a busy chip.
+  const int wm_ = (wave / C::WN), wn_ = (wave % C::WN);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.bias), 0, a.bias != nullptr ? a.cout * 4 : 0, 0x00020000);
+  f32x4 bias_v[C::NT][4];           // channels past cout (and a null bias) read as zero
+#pragma unroll
+  for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int nn = n0 + wn_ * (C::NT * 32) + nt * 32 + 8 * j + 4 * (lane >> 5);
+      const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (uint32_t)(nn * 4), 0, 0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bias_v[nt][j][e] = __uint_as_float(t[e]);
+    }
+
+  f32x16 acc[C::MT][C::NT];
+#pragma unroll
+  for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.0f;
+
+  constexpr uint32_t kOob = 0x80000000u;   // >= num_records for every tensor this kernel accepts
+  const Geom geom{a.H, a.W, a.cout, x0, y0, n0, lane, wave, grp, wm, wn, r, h};
+  const Phase<T> ph1{xin, wgt, a.cin, w_blocked, relu_floor};
+  conv_mainloop<C>(ph1, geom, smem, acc);
   STV_STAMP(2);
+
+  // ---- fused second term (3x3 kernels only): the ReLU mask belongs to the first term alone, so it
+  // is applied to the accumulators now - `ref` is read in their layout - and the 1x1 product of
+  // (x2, w2) then lands on top, same tile, same registers.  The separate launch it replaces also
+  // had to read-modify-write this output.
+  bool mask_done = false;
+  if constexpr (C::TAPS == 9) {
+    if (a.x2 != nullptr) {
+      if (a.flags & STV_MASK) {
+        const int ref_bytes = a.H * a.W * a.cout * (int)sizeof(T);
+        const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.ref), 0, ref_bytes, 0x00020000);
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt) {
+          const int gy = y0 + wm * C::MT + mt, gx = x0 + r;
+          const bool pok = gy < a.H && gx < a.W;
+#pragma unroll
+          for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int nn = n0 + wn * (C::NT * 32) + nt * 32 + 8 * j + 4 * h;
+              const uint32_t off = (pok && nn < a.cout) ? (uint32_t)((((gy * a.W + gx) * a.cout) + nn) * (int)sizeof(T)) : kOob;
+              if constexpr (sizeof(T) == 4) {
+                const u32x4 m = __builtin_amdgcn_raw_buffer_load_b128(rs_m, off, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[mt][nt][4 * j + e] = (__uint_as_float(m[e]) > 0.0f) ? acc[mt][nt][4 * j + e] : 0.0f;
+              } else {
+                const auto m = __builtin_amdgcn_raw_buffer_load_b64(rs_m, off, 0, 0);
+                acc[mt][nt][4 * j + 0] = ((int)(m[0] << 16) > 0) ? acc[mt][nt][4 * j + 0] : 0.0f;
+                acc[mt][nt][4 * j + 1] = ((int)(m[0] & 0xFFFF0000u) > 0) ? acc[mt][nt][4 * j + 1] : 0.0f;
+                acc[mt][nt][4 * j + 2] = ((int)(m[1] << 16) > 0) ? acc[mt][nt][4 * j + 2] : 0.0f;
+                acc[mt][nt][4 * j + 3] = ((int)(m[1] & 0xFFFF0000u) > 0) ? acc[mt][nt][4 * j + 3] : 0.0f;
+              }
+            }
+        }
+        mask_done = true;
+      }
+      using C1 = Cfg<T, C::TH, C::BN, C::WM, C::WN, 1, C::KS, C::NBUF>;
+      static_assert(C1::RING_BYTES <= C::LDS_BYTES, "the 1x1 pass reuses the 3x3 ring");
+      const Phase<T> ph2{static_cast<const T*>(a.x2), static_cast<const T*>(a.w2), a.cin2, false,
+                         sizeof(T) == 2 ? 0x80008000u : 0x80000000u};
+      conv_mainloop<C1>(ph2, geom, smem, acc);
+    }
+  }
 
   // ---- epilogue, in registers ----------------------------------------------------------------
   // A lane holds, per (row block, 32-channel block), 4 groups of 4 consecutive channels of ONE
@@ -367,7 +445,7 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
   // 16-byte stores per 32 channels, no LDS round trip and no barrier.  Only the K-split variant
   // still meets in LDS (the second group's partial sums).
   const bool relu_out = (a.flags & STV_RELU_OUT) != 0;
-  const bool do_mask = (a.flags & STV_MASK) != 0;
+  const bool do_mask = (a.flags & STV_MASK) != 0 && !mask_done;
   const bool do_acc = (a.flags & STV_ACCUM) != 0;
   const int out_bytes = a.H * a.W * a.cout * (int)sizeof(T);
   const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, out_bytes, 0x00020000);
@@ -663,7 +741,7 @@ int tune_typed(int H, int W, int cin, int cout, int taps, hipStream_t st) {
   const size_t words = (bx + bw) / 4;
   hipLaunchKernelGGL(tune_fill_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st,
                      reinterpret_cast<uint32_t*>(buf), words, 0x9E3779B9u);
-  ConvArgs a{buf, buf + bx, nullptr, nullptr, buf + bx + bw, H, W, cin, cout, STV_W_BLOCKED, nullptr};
+  ConvArgs a{buf, buf + bx, nullptr, nullptr, buf + bx + bw, H, W, cin, cout, STV_W_BLOCKED, nullptr, nullptr, nullptr, 0};
   if (taps == 1) a.flags = 0;
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
@@ -734,7 +812,7 @@ extern "C" int stv_conv_igemm(const void* x, const void* w, const float* bias, c
   // the direct fallback (shapes the matrix-core tiling does not cover) reads plain weights only
   if ((flags & STV_W_BLOCKED) && choose_cfg(H, W, cin, cout, dtype == STV_F32 ? 4 : 2, taps) < 0) return STV_ERR_ARG;
   if ((size_t)H * W * (size_t)(cin > cout ? cin : cout) >= (size_t)1 << 31) return STV_ERR_ARG;
-  ConvArgs a{x, w, bias, ref, y, H, W, cin, cout, flags, nullptr};
+  ConvArgs a{x, w, bias, ref, y, H, W, cin, cout, flags, nullptr, nullptr, nullptr, 0};
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dtype == STV_F32)
     return taps == 9 ? launch_typed<float, 9>(a, st) : launch_typed<float, 1>(a, st);
@@ -751,7 +829,24 @@ extern "C" int stv_conv_igemm_pool(const void* x, const void* w, const float* bi
   if (dtype != STV_F32 && dtype != STV_BF16) return STV_ERR_ARG;
   // the fused pool lives in the matrix-core kernel's epilogue: other shapes pool separately
   if (choose_cfg(H, W, cin, cout, dtype == STV_F32 ? 4 : 2, 9) < 0) return STV_ERR_ARG;
-  ConvArgs a{x, w, bias, nullptr, y, H, W, cin, cout, flags, y_pool};
+  ConvArgs a{x, w, bias, nullptr, y, H, W, cin, cout, flags, y_pool, nullptr, nullptr, 0};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  return dtype == STV_F32 ? launch_typed<float, 9>(a, st) : launch_typed<bf16_t, 9>(a, st);
+}
+
+extern "C" int stv_conv_igemm_dual(const void* x, const void* w, const void* x2, const void* w2, const void* ref,
+                                   void* y, int H, int W, int cin, int cin2, int cout, int flags, int dtype,
+                                   void* stream) {
+  if (!x || !w || !x2 || !w2 || !y || H <= 0 || W <= 0 || cin <= 0 || cin2 <= 0 || cout <= 0) return STV_ERR_ARG;
+  if ((flags & STV_MASK) && !ref) return STV_ERR_ARG;
+  if (flags & (STV_RELU_IN | STV_RELU_OUT)) return STV_ERR_ARG;             // a gradient path: no activations
+  if (dtype != STV_F32 && dtype != STV_BF16) return STV_ERR_ARG;
+  const size_t cmax = (size_t)(cin > cout ? cin : cout) > (size_t)cin2 ? (size_t)(cin > cout ? cin : cout) : (size_t)cin2;
+  if ((size_t)H * W * cmax >= (size_t)1 << 31) return STV_ERR_ARG;
+  const int es = dtype == STV_F32 ? 4 : 2;
+  // both terms run in the matrix-core kernel: its channel granularity applies to both K extents
+  if (choose_cfg(H, W, cin, cout, es, 9) < 0 || cin2 % (32 / es)) return STV_ERR_ARG;
+  ConvArgs a{x, w, nullptr, ref, y, H, W, cin, cout, flags, nullptr, x2, w2, cin2};
   hipStream_t st = static_cast<hipStream_t>(stream);
   return dtype == STV_F32 ? launch_typed<float, 9>(a, st) : launch_typed<bf16_t, 9>(a, st);
 }

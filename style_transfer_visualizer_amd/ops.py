@@ -184,6 +184,27 @@ def conv_igemm_pool(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None,
     return out, pool_out
 
 
+def conv_igemm_dual(x: torch.Tensor, w: torch.Tensor, x2: torch.Tensor, w2: torch.Tensor,
+                    ref: torch.Tensor | None = None, out: torch.Tensor | None = None, flags: int = 0) -> torch.Tensor:
+    """out = [out +] mask(ref>0) * conv3x3(x, w) + x2 . w2^T in one launch (stv_conv_igemm_dual)."""
+    H, W, cin = x.shape
+    if w.dim() == 4:
+        _, nck, cout, ck = w.shape
+        flags |= W_BLOCKED
+    else:
+        _, cout, _ = w.shape
+    cin2 = x2.shape[2]
+    if out is None:
+        if flags & ACCUM:
+            msg = "ACCUM needs an existing output tensor"
+            raise RuntimeError(msg)
+        out = torch.empty(H, W, cout, device=x.device, dtype=x.dtype)
+    lib = _lib.load()
+    _lib.check(lib.stv_conv_igemm_dual(_ptr(x), _ptr(w), _ptr(x2), _ptr(w2), _ptr(ref), _ptr(out), H, W, cin, cin2,
+                                       cout, flags, dtype_code(x.dtype), _stream()), "stv_conv_igemm_dual")
+    return out
+
+
 # ---- pool / relu --------------------------------------------------------------
 
 def maxpool_fwd(x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:

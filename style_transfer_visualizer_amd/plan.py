@@ -276,9 +276,13 @@ class Schedule:
             return ACCUM if id(buf) in written else 0
 
         n_style = len(self.style_taps)
+        fuse_gram = os.environ.get("STV_FUSE_GRAM", "1") != "0"      # A/B knob
+        fused_taps: set[int] = set()     # style taps whose dF = F.S rides in the dgrad that shares their buffer
         for nd in reversed(self.nodes):
             d = nd.dst
             for tap in d.taps:
+                if id(tap) in fused_taps:
+                    continue
                 if tap.kind == "style":
                     if d.act.is_cuda:
                         ops.conv_tune(d.H, d.W, d.C, d.C, 1, self.dtype)     # cached per shape
@@ -303,8 +307,21 @@ class Schedule:
             mask_src = nd.relu_in or (s.relu_fused and not s.taps)
             if nd.kind == "conv":
                 flags = (MASK if mask_src else 0) | acc_flag(s) | (W_BLOCKED if nd.wb.dim() == 4 else 0)
-                out.append(self._op(op=OP_CONV, p0=d.grad, p1=nd.wb, p3=s.act if mask_src else None, q0=s.grad,
-                                    H=s.H, W=s.W, cin=d.C, cout=s.C, taps=9, flags=flags))
+                # A Gram tap on the pre-ReLU output s: its gradient term F.S lands on the same buffer
+                # as this dgrad.  One launch computes mask * dgrad + F.S (stv_conv_igemm_dual) instead
+                # of a second launch that re-reads and re-writes s.grad.
+                gram = None
+                if (fuse_gram and nd.wb.dim() == 4 and s.act.is_cuda and not (s.relu_fused and s.taps)
+                        and s.C % (32 // s.act.element_size()) == 0):
+                    gram = next((t for t in s.taps if t.kind == "style" and t.sgrad is not None), None)
+                if gram is not None:
+                    fused_taps.add(id(gram))
+                    out.append(self._op(op=OP_CONV, p0=d.grad, p1=nd.wb, p3=s.act if mask_src else None, q0=s.grad,
+                                        q2=s.act, q3=gram.sgrad, n=s.C, H=s.H, W=s.W, cin=d.C, cout=s.C, taps=9,
+                                        flags=flags))
+                else:
+                    out.append(self._op(op=OP_CONV, p0=d.grad, p1=nd.wb, p3=s.act if mask_src else None, q0=s.grad,
+                                        H=s.H, W=s.W, cin=d.C, cout=s.C, taps=9, flags=flags))
             elif nd.kind == "pool":
                 flags = (MASK if (s.relu_fused and not s.taps) else 0) | acc_flag(s)
                 out.append(self._op(op=OP_POOL_BWD, p0=s.act, p1=d.grad, q0=s.grad, H=s.H, W=s.W, cin=s.C,

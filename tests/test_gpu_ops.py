@@ -131,6 +131,37 @@ def test_conv_igemm_forward(dtype, case, flags, blocked):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [None, 0, 1, 3, 4, 5, 7])
+@pytest.mark.parametrize("flags", [0, ops.MASK, ops.ACCUM, ops.MASK | ops.ACCUM])
+@pytest.mark.parametrize("case", [(128, 64, 33, 70), (256, 128, 16, 40), (64, 64, 9, 33), (512, 256, 8, 8)])
+def test_conv_igemm_dual_dgrad_plus_gram_term(dtype, cfg, flags, case, monkeypatch):
+    """out = [prev +] mask(z>0) * dgrad(dy, w) + F . S^T in one launch: the mask touches the first term only."""
+    cd, cs, H, W = case            # channels of the layer above (dy) and of this layer (output, F, S)
+    if cfg is not None:
+        if cs <= 64 and cfg in (0, 2):
+            pytest.skip("128-channel tiles need more than 64 output channels")
+        monkeypatch.setenv("STV_CONV_CFG", str(cfg))
+    w = rnd((cd, cs, 3, 3), 71, -1, 1) * (2.0 / (9 * cd)) ** 0.5
+    dy = rnd((1, cd, H, W), 72)
+    z = rnd((1, cs, H, W), 73)                      # this layer's stored pre-ReLU output = F
+    s_mat = rnd((cs, cs), 74, -0.02, 0.02)
+    s_mat = (s_mat + s_mat.t()) * 0.5
+    prev = rnd((1, cs, H, W), 75)
+    wq, dyq, zq, sq, pq = q(w, dtype), q(dy, dtype), q(z, dtype), q(s_mat, dtype), q(prev, dtype)
+    xr = torch.zeros(1, cs, H, W, requires_grad=True)
+    F.conv2d(xr, wq, None, padding=1).backward(dyq)
+    first = xr.grad * ((zq > 0).float() if flags & ops.MASK else 1.0)
+    second = torch.einsum("bchw,nc->bnhw", zq, sq)
+    ref = first + second + (pq if flags & ops.ACCUM else 0.0)
+    out = ops.to_nhwc(prev, dtype).to(DEV)
+    wb = ops.block_weights(ops.pack_weights_bwd(w).to(dtype).to(DEV))
+    zn = ops.to_nhwc(z, dtype).to(DEV)
+    ops.conv_igemm_dual(ops.to_nhwc(dy, dtype).to(DEV), wb, zn, sq.to(dtype).to(DEV).contiguous(),
+                        ref=zn if flags & ops.MASK else None, out=out, flags=flags)
+    assert_close(ops.from_nhwc(out), ref, dtype, 9 * cd + cs, f"dual {case} flags={flags}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cfg", [None, 0, 1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("case", [(64, 64, 33, 70), (128, 128, 16, 40), (64, 128, 9, 33), (256, 256, 8, 8)])
 def test_conv_igemm_with_fused_maxpool(dtype, cfg, case, monkeypatch):
