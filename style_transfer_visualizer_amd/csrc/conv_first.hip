@@ -425,53 +425,73 @@ __global__ __launch_bounds__(256) void conv_first_dgrad_mfma(const bf16_t* __res
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int tiles_x = (W + DG_TW - 1) / DG_TW;
-  const int x0 = (blockIdx.x % tiles_x) * DG_TW, y0 = (blockIdx.x / tiles_x) * DG_TH;
+  const int ntiles = tiles_x * ((H + DG_TH - 1) / DG_TH);
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
-  for (int i = tid; i < (DG_TH + 2) * DG_IW * 8; i += 256) {
-    const int p = i >> 3, v = i & 7;
-    const int gy = y0 + p / DG_IW - 1, gx = x0 + p % DG_IW - 1;
-    const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
-    *reinterpret_cast<u32x4*>(tile + p * DG_PITCH + v * 16) =
-        ok ? *reinterpret_cast<const u32x4*>(dy + ((size_t)gy * W + gx) * 64 + v * 8) : zero4;
-  }
+  // Persistent workgroup: the dy halo tile of the NEXT image tile is requested into registers
+  // before the current one is multiplied, so the HBM round trip overlaps the MFMA phase.
+  constexpr int NVEC = (DG_TH + 2) * DG_IW * 8;              // 16-byte vectors of a halo tile
+  constexpr int NPRE = (NVEC + 255) / 256;
+  u32x4 pre[NPRE];
+  auto request = [&](int t) {
+    const int tx0 = (t % tiles_x) * DG_TW, ty0 = (t / tiles_x) * DG_TH;
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) {
+      const int i = k * 256 + tid;
+      const int p = i >> 3, v = i & 7;
+      const int gy = ty0 + p / DG_IW - 1, gx = tx0 + p % DG_IW - 1;
+      const bool ok = i < NVEC && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      pre[k] = ok ? *reinterpret_cast<const u32x4*>(dy + ((size_t)gy * W + gx) * 64 + v * 8) : zero4;
+    }
+  };
+  request(blockIdx.x);
   for (int i = tid; i < DG_FRAGS; i += 256) wtab[i] = *reinterpret_cast<const u32x4*>(frag + 4 * i);
   if (tid == 0) wtab[DG_FRAGS] = zero4;
-  __syncthreads();
   typedef __attribute__((ext_vector_type(4))) float acc_t;
-  acc_t acc[4];
-#pragma unroll
-  for (int mb = 0; mb < 4; ++mb) acc[mb] = acc_t{0.0f, 0.0f, 0.0f, 0.0f};
   // B column = lane & 15: columns 0..2 are the three image channels, the rest multiply zeros
   const int ent = (r < 3) ? r * 4 + g : -1;
+  const size_t plane = (size_t)H * W;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int x0 = (t % tiles_x) * DG_TW, y0 = (t / tiles_x) * DG_TH;
+    __syncthreads();                      // every wave is done reading the previous tile
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) {
+      const int i = k * 256 + tid;
+      if (i < NVEC) *reinterpret_cast<u32x4*>(tile + (i >> 3) * DG_PITCH + (i & 7) * 16) = pre[k];
+    }
+    if (t + (int)gridDim.x < ntiles) request(t + gridDim.x);
+    __syncthreads();
+    acc_t acc[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) acc[mb] = acc_t{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll 1
-  for (int tap = 0; tap < 9; ++tap) {
-    const int dyo = tap / 3, dxo = tap - dyo * 3;
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dyo = tap / 3, dxo = tap - dyo * 3;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int fb = ((tap * 2 + ks) * 2) * 12;
-      const bf16x8v b_hi = __builtin_bit_cast(bf16x8v, wtab[ent >= 0 ? fb + ent : DG_FRAGS]);
-      const bf16x8v b_lo = __builtin_bit_cast(bf16x8v, wtab[ent >= 0 ? fb + 12 + ent : DG_FRAGS]);
+      for (int ks = 0; ks < 2; ++ks) {
+        const int fb = ((tap * 2 + ks) * 2) * 12;
+        const bf16x8v b_hi = __builtin_bit_cast(bf16x8v, wtab[ent >= 0 ? fb + ent : DG_FRAGS]);
+        const bf16x8v b_lo = __builtin_bit_cast(bf16x8v, wtab[ent >= 0 ? fb + 12 + ent : DG_FRAGS]);
 #pragma unroll
-      for (int mb = 0; mb < 4; ++mb) {
-        const int row = wave * 2 + (mb >> 1) + dyo, col = (mb & 1) * 16 + r + dxo;
-        const bf16x8v a = __builtin_bit_cast(
-            bf16x8v, *reinterpret_cast<const u32x4*>(tile + (row * DG_IW + col) * DG_PITCH + ks * 64 + g * 16));
-        acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b_lo, acc[mb], 0, 0, 0);
-        acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b_hi, acc[mb], 0, 0, 0);
+        for (int mb = 0; mb < 4; ++mb) {
+          const int row = wave * 2 + (mb >> 1) + dyo, col = (mb & 1) * 16 + r + dxo;
+          const bf16x8v a = __builtin_bit_cast(
+              bf16x8v, *reinterpret_cast<const u32x4*>(tile + (row * DG_IW + col) * DG_PITCH + ks * 64 + g * 16));
+          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b_lo, acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b_hi, acc[mb], 0, 0, 0);
+        }
       }
     }
-  }
-  // D: column (lane & 15) = channel, rows 4g..4g+3 = pixels of the 16-pixel block
-  if (r < 3) {
-    const size_t plane = (size_t)H * W;
+    // D: column (lane & 15) = channel, rows 4g..4g+3 = pixels of the 16-pixel block
+    if (r < 3) {
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
-      const int gy = y0 + wave * 2 + (mb >> 1);
-      if (gy >= H) continue;
+      for (int mb = 0; mb < 4; ++mb) {
+        const int gy = y0 + wave * 2 + (mb >> 1);
+        if (gy >= H) continue;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int gx = x0 + (mb & 1) * 16 + 4 * g + i;
-        if (gx < W) dx[r * plane + (size_t)gy * W + gx] = acc[mb][i];
+        for (int i = 0; i < 4; ++i) {
+          const int gx = x0 + (mb & 1) * 16 + 4 * g + i;
+          if (gx < W) dx[r * plane + (size_t)gy * W + gx] = acc[mb][i];
+        }
       }
     }
   }
@@ -588,7 +608,8 @@ int dgrad_typed(const void* dy, const float* wf, const float* packed, float* dx,
   if (cin == 3 && cout == 64 && packed && std::is_same<T, bf16_t>::value && !getenv("STV_FIRST_VALU")) {
     const int tiles = ceil_div(W, DG_TW) * ceil_div(H, DG_TH);
     constexpr int lds = DG_TILE_BYTES + (DG_FRAGS + 1) * 16;
-    hipLaunchKernelGGL(conv_first_dgrad_mfma, dim3(tiles), dim3(256), lds, st, static_cast<const bf16_t*>(dy),
+    const int grid = tiles < 2 * 256 ? tiles : 2 * 256;       // two resident workgroups per CU walk the tiles
+    hipLaunchKernelGGL(conv_first_dgrad_mfma, dim3(grid), dim3(256), lds, st, static_cast<const bf16_t*>(dy),
                        reinterpret_cast<const uint32_t*>(packed + 2 * 1728 + MF_FRAG_WORDS), dx, H, W);
     STV_CHECK_LAUNCH();
     return STV_OK;

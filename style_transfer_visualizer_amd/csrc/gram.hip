@@ -17,6 +17,8 @@
 //                    dF^T = F^T * S is a plain 1x1 conv (stv_conv_igemm taps=1).
 #include <type_traits>
 
+#include <stdlib.h>
+
 #include "stv_common.h"
 
 namespace {
@@ -422,7 +424,8 @@ extern "C" int stv_gram_ksplit(int n_pixels, int channels) {
   const int TS = gram_tile(channels);
   const int nt = ceil_div(channels, TS);
   const int pairs = nt * (nt + 1) / 2;
-  const int lo = ceil_div(128, pairs), hi = (512 / pairs) > 0 ? 512 / pairs : 1;
+  static const int wg_max = getenv("STV_GRAM_WGS") ? atoi(getenv("STV_GRAM_WGS")) : 512;     // tuning aid
+  const int lo = ceil_div(128, pairs), hi = (wg_max / pairs) > 0 ? wg_max / pairs : 1;
   int ks = n_pixels / (2 * channels);
   if (ks < lo) ks = lo;
   if (ks > hi) ks = hi;
