@@ -312,6 +312,7 @@ __device__ __forceinline__ void conv_mainloop(const Phase<typename C::Elem>& ph,
   }
   wait_vmcnt<(C::NBUF - 2) * C::PPW>();
   __builtin_amdgcn_s_barrier();
+  STV_STAMP(1);
 
   int c = 0;
   if (C::NBUF == 3) {
