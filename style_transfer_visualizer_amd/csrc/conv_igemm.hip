@@ -755,7 +755,7 @@ int tune_typed(int H, int W, int cin, int cout, int taps, hipStream_t st) {
   if (const char* lim = getenv("STV_CONV_TUNE_CFGS")) ncfg = atoi(lim) < kNumCfg ? atoi(lim) : kNumCfg;   // A/B aid
   for (int cfg = 0; cfg < ncfg && rc == STV_OK; ++cfg) {
     if (!cfg_valid(cfg, cout)) continue;
-    constexpr int kWarm = 2, kReps = 6;
+    constexpr int kWarm = 3, kReps = 10;
     for (int i = 0; i < kWarm && rc == STV_OK; ++i)
       rc = taps == 9 ? launch_mfma<T, 9>(a, cfg, st) : launch_mfma<T, 1>(a, cfg, st);
     (void)hipEventRecord(e0, st);
