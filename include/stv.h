@@ -235,6 +235,9 @@ int stv_program_run(stv_program* prog, int use_graph, void* stream);
 /* Measurement helper: eager run with a hipEvent pair around every op (recorded on
  * `stream`); ms_out[i] = device milliseconds of op i.  Synchronises. */
 int stv_program_profile(stv_program* prog, void* stream, float* ms_out, int n_out);
+/* The same with each op launched `reps` times back to back inside its event pair (time divided by
+ * reps): amortises the event pair's own few microseconds.  Leaves the buffers meaningless. */
+int stv_program_profile_reps(stv_program* prog, void* stream, int reps, float* ms_out, int n_out);
 int stv_program_op_count(const stv_program* prog);
 void stv_program_destroy(stv_program* prog);
 

@@ -76,6 +76,7 @@ SIGNATURES = {
     "stv_program_create": (c_int, [ctypes.POINTER(StvOp), c_int, ctypes.POINTER(c_void_p)]),
     "stv_program_run": (c_int, [c_void_p, c_int, c_void_p]),
     "stv_program_profile": (c_int, [c_void_p, c_void_p, ctypes.POINTER(c_float), c_int]),
+    "stv_program_profile_reps": (c_int, [c_void_p, c_void_p, c_int, ctypes.POINTER(c_float), c_int]),
     "stv_program_op_count": (c_int, [c_void_p]),
     "stv_program_destroy": (None, [c_void_p]),
 }

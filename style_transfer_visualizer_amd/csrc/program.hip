@@ -198,7 +198,15 @@ extern "C" int stv_program_run(stv_program* prog, int use_graph, void* stream) {
 // kernels are launched on; ms_out[i] = device time of op i.  Synchronises at
 // the end (measurement helper for bench.py, never used on the step path).
 extern "C" int stv_program_profile(stv_program* prog, void* stream, float* ms_out, int n_out) {
-  if (!prog || !ms_out || n_out < (int)prog->ops.size()) return STV_ERR_ARG;
+  return stv_program_profile_reps(prog, stream, 1, ms_out, n_out);
+}
+
+// The same with every op launched `reps` times back to back inside its event pair and the time
+// divided by reps: the event pair's own cost (a few microseconds, comparable to a short kernel)
+// is amortised, so ms_out approaches the kernel durations a tracing profiler reports.  Ops that
+// accumulate into their output do so `reps` times: the buffers are left meaningless - timing only.
+extern "C" int stv_program_profile_reps(stv_program* prog, void* stream, int reps, float* ms_out, int n_out) {
+  if (!prog || !ms_out || reps < 1 || n_out < (int)prog->ops.size()) return STV_ERR_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t n = prog->ops.size();
   std::vector<hipEvent_t> ev(n + 1);
@@ -207,13 +215,15 @@ extern "C" int stv_program_profile(stv_program* prog, void* stream, float* ms_ou
   int rc = STV_OK;
   (void)hipEventRecord(ev[0], st);
   for (size_t i = 0; i < n && rc == STV_OK; ++i) {
-    rc = run_op(prog->ops[i], stream);
+    for (int k = 0; k < reps && rc == STV_OK; ++k) rc = run_op(prog->ops[i], stream);
     (void)hipEventRecord(ev[i + 1], st);
   }
   if (hipStreamSynchronize(st) != hipSuccess) rc = STV_ERR_LAUNCH;
   if (rc == STV_OK)
-    for (size_t i = 0; i < n; ++i)
+    for (size_t i = 0; i < n; ++i) {
       if (hipEventElapsedTime(&ms_out[i], ev[i], ev[i + 1]) != hipSuccess) rc = STV_ERR_LAUNCH;
+      ms_out[i] /= (float)reps;
+    }
   for (auto& e : ev) (void)hipEventDestroy(e);
   return rc;
 }

@@ -353,12 +353,13 @@ class Program:
         _lib.check(lib.stv_program_run(self._handle, 1 if use_graph else 0,
                                        torch.cuda.current_stream().cuda_stream), "stv_program_run")
 
-    def profile(self) -> list[float]:
-        """Per-op device milliseconds (HIP events on the current stream); synchronises."""
+    def profile(self, reps: int = 1) -> list[float]:
+        """Per-op device milliseconds (HIP events on the current stream); synchronises.  ``reps`` > 1
+        launches every op that many times inside its event pair (timing only: buffers are then garbage)."""
         lib = _lib.load()
         out = (ctypes.c_float * self.n_ops)()
-        _lib.check(lib.stv_program_profile(self._handle, torch.cuda.current_stream().cuda_stream, out,
-                                           self.n_ops), "stv_program_profile")
+        _lib.check(lib.stv_program_profile_reps(self._handle, torch.cuda.current_stream().cuda_stream, int(reps), out,
+                                                self.n_ops), "stv_program_profile_reps")
         return list(out)
 
     def __del__(self) -> None:
