@@ -425,7 +425,8 @@ extern "C" int stv_gram_ksplit(int n_pixels, int channels) {
   const int nt = ceil_div(channels, TS);
   const int pairs = nt * (nt + 1) / 2;
   static const int wg_max = getenv("STV_GRAM_WGS") ? atoi(getenv("STV_GRAM_WGS")) : 512;     // tuning aid
-  const int lo = ceil_div(128, pairs), hi = (wg_max / pairs) > 0 ? wg_max / pairs : 1;
+  static const int wg_min = getenv("STV_GRAM_WGS_MIN") ? atoi(getenv("STV_GRAM_WGS_MIN")) : 128;
+  const int lo = ceil_div(wg_min, pairs), hi = (wg_max / pairs) > 0 ? wg_max / pairs : 1;
   int ks = n_pixels / (2 * channels);
   if (ks < lo) ks = lo;
   if (ks > hi) ks = hi;
