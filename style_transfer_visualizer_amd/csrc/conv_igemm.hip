@@ -738,7 +738,10 @@ int tune_typed(int H, int W, int cin, int cout, int taps, hipStream_t st) {
   const size_t nx = (size_t)H * W * cin, nw = (size_t)taps * cout * cin, ny = (size_t)H * W * cout;
   char* buf = nullptr;
   const size_t bx = (nx * sizeof(T) + 255) / 256 * 256, bw = (nw * sizeof(T) + 255) / 256 * 256;
-  if (hipMalloc(reinterpret_cast<void**>(&buf), bx + bw + ny * sizeof(T)) != hipSuccess) return -(100 + STV_ERR_ALLOC);
+  if (hipMalloc(reinterpret_cast<void**>(&buf), bx + bw + ny * sizeof(T)) != hipSuccess) {
+    (void)hipGetLastError();                       // no room for scratch copies: keep the analytic choice
+    return model_cfg(H, W, cin, cout);
+  }
   const size_t words = (bx + bw) / 4;
   hipLaunchKernelGGL(tune_fill_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st,
                      reinterpret_cast<uint32_t*>(buf), words, 0x9E3779B9u);
