@@ -8,7 +8,7 @@ reps = int(sys.argv[6]) if len(sys.argv) > 6 else 5
 os.environ["STV_CONV_CFG"] = str(cfg)
 dev = torch.device("cuda")
 x = torch.randn(H, W, cin, device=dev).bfloat16()
-w = (torch.randn(9, cout, cin, device=dev) * 0.02).bfloat16()
+w = ops.block_weights((torch.randn(9, cout, cin, device=dev) * 0.02).bfloat16())
 b = torch.zeros(cout, device=dev)
 y = torch.empty(H, W, cout, device=dev, dtype=torch.bfloat16)
 for _ in range(reps):
