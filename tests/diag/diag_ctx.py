@@ -1,6 +1,6 @@
 """Recompute every conv-produced gradient of a program from the program's own buffers, op by op (diagnostic)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, torch.nn.functional as F
 from tests.conftest import GoldenCase
 from style_transfer_visualizer_amd import core_model, ops

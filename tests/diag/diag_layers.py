@@ -1,6 +1,6 @@
 """Layer-by-layer activation/gradient comparison HIP vs torch-CPU autograd at one image (diagnostic)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import torch.nn.functional as F
 from tests.conftest import GoldenCase

@@ -1,6 +1,6 @@
 """Isolate the device L-BFGS from the conv kernels: CPU-oracle gradients fed to both optimizers."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from tests.conftest import GoldenCase
 from oracle import core_model_ref as ocm, optim_ref

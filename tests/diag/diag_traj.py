@@ -1,6 +1,6 @@
 """Per-step: HIP gradient vs CPU-oracle gradient evaluated at the SAME x, and x drift vs the oracle trajectory."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from tests.conftest import GoldenCase
 from oracle import core_model_ref as ocm, optim_ref
