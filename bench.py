@@ -67,7 +67,7 @@ def kernel_group(meta, OP, dtype_code: int = 1) -> str | None:
         return f"conv_igemm_kernel<Cfg<{elem}, {_CFG_NAMES[cfg]}, {taps}, {_CFG_KS[cfg]}>>"
     names = {OP["CONV_FIRST_FWD"]: "conv_first_fwd", OP["CONV_FIRST_DGRAD"]: "conv_first_dgrad",
              OP["POOL_FWD"]: "maxpool_fwd", OP["POOL_BWD"]: "maxpool_bwd", OP["GRAM_PARTIAL"]: "gram_partial",
-             OP["GRAM_FINISH"]: "gram_finish", OP["CONTENT_LOSS"]: "content_loss",
+             OP["GRAM_FINISH"]: "gram_finish", OP["GRAM_MULTI"]: "gram_multi (batched partial + finish)", OP["CONTENT_LOSS"]: "content_loss",
              OP["CONTENT_GRAD"]: "content_grad", OP["LOSS_COMBINE"]: "loss_combine",
              OP["RELU_FWD"]: "relu_fwd", OP["RELU_BWD"]: "relu_bwd"}
     return names.get(op)

@@ -161,6 +161,25 @@ int stv_gram_finish(const float* partials, const float* target, float* gram_out,
                     float* loss_part, void* sgrad, int n_pixels, int C, float clamp_max,
                     float norm, float coef, const float* coef_dev, int dtype, void* stream);
 
+/* The Gram chain of several taps (layers) in one call: one batched stv_gram_partial launch per
+ * tile size present plus one batched stv_gram_finish launch, instead of two launches per tap.
+ * The chain of a step is five small latency-bound problems; side by side in one grid they cost
+ * the slowest, not the sum.  Fields as the arguments of the two calls above; at most 8 taps.
+ * (The finish of a tap with hundreds of slabs sums them in a different - still fixed - order
+ * than stv_gram_finish: results agree to fp32 rounding.) */
+typedef struct {
+  const void* F;          /* features, NHWC [n_pixels][channels] in `dtype` */
+  float* partials;        /* stv_gram_partials_bytes(n_pixels, channels) */
+  const float* target;    /* [C][C] or NULL */
+  float* gram_out;        /* [C][C] or NULL */
+  float* loss_part;       /* stv_gram_loss_parts(channels) floats, or NULL */
+  void* sgrad;            /* backward seed [C][C] in `dtype`, or NULL */
+  const float* coef_dev;  /* optional device scalar multiplying the seed */
+  int n_pixels, channels;
+  float clamp_max, norm, coef;
+} stv_gram_tap_t;
+int stv_gram_multi(const stv_gram_tap_t* taps, int n_taps, int dtype, void* stream);
+
 /* ---- Content loss: mse_loss(features, target) (core_model.py:295). -------- */
 #define STV_CONTENT_LOSS_PARTS 256
 int stv_content_loss(const void* F, const void* target, float* loss_part, size_t n,
@@ -210,7 +229,7 @@ enum {
   STV_OP_CONV_FIRST_FWD = 1, STV_OP_CONV_FIRST_DGRAD, STV_OP_CONV, STV_OP_POOL_FWD,
   STV_OP_POOL_BWD, STV_OP_RELU_FWD, STV_OP_RELU_BWD, STV_OP_GRAM_PARTIAL,
   STV_OP_GRAM_FINISH, STV_OP_CONTENT_LOSS, STV_OP_CONTENT_GRAD, STV_OP_LOSS_COMBINE,
-  STV_OP_MEMSET
+  STV_OP_MEMSET, STV_OP_GRAM_MULTI
 };
 /* Scheduling hints in stv_op_t.flags (masked off before the kernel sees them):
  * an op with STV_LANE_SIDE may run concurrently with the ops after it: it reads only
@@ -221,7 +240,9 @@ enum { STV_LANE_SIDE = 1 << 29, STV_LANE_JOIN = 1 << 30 };
 /* Operands follow the direct entry points' argument order (inputs p0.., outputs q0..).
  * CONV_FIRST_FWD takes the optional stv_conv_first_pack buffer in p3, CONV_FIRST_DGRAD in p2;
  * CONV with q1 set runs stv_conv_igemm_pool (q1 = pooled output); CONV with q2/q3 set runs
- * stv_conv_igemm_dual (q2 = x2, q3 = w2, n = cin2: inputs, despite the slot names). */
+ * stv_conv_igemm_dual (q2 = x2, q3 = w2, n = cin2: inputs, despite the slot names).
+ * GRAM_MULTI: p0 = HOST pointer to an array of stv_gram_tap_t, n = its length; the array is
+ * copied into the program when it is created. */
 typedef struct {
   int32_t op, dtype, flags, taps;
   int32_t H, W, cin, cout;

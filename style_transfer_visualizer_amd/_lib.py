@@ -18,7 +18,7 @@ LANE_SIDE, LANE_JOIN = 1 << 29, 1 << 30          # scheduling hints of the comma
 
 (OP_CONV_FIRST_FWD, OP_CONV_FIRST_DGRAD, OP_CONV, OP_POOL_FWD, OP_POOL_BWD, OP_RELU_FWD,
  OP_RELU_BWD, OP_GRAM_PARTIAL, OP_GRAM_FINISH, OP_CONTENT_LOSS, OP_CONTENT_GRAD,
- OP_LOSS_COMBINE, OP_MEMSET) = range(1, 14)
+ OP_LOSS_COMBINE, OP_MEMSET, OP_GRAM_MULTI) = range(1, 15)
 
 CONTENT_LOSS_PARTS = 256
 
@@ -36,6 +36,17 @@ class StvOp(ctypes.Structure):
         ("f0", c_float), ("f1", c_float), ("f2", c_float), ("f3", c_float),
         ("p0", c_void_p), ("p1", c_void_p), ("p2", c_void_p), ("p3", c_void_p),
         ("q0", c_void_p), ("q1", c_void_p), ("q2", c_void_p), ("q3", c_void_p),
+    ]
+
+
+class StvGramTap(ctypes.Structure):
+    """Mirror of ``stv_gram_tap_t`` (include/stv.h)."""
+
+    _fields_ = [
+        ("F", c_void_p), ("partials", c_void_p), ("target", c_void_p), ("gram_out", c_void_p),
+        ("loss_part", c_void_p), ("sgrad", c_void_p), ("coef_dev", c_void_p),
+        ("n_pixels", c_int32), ("channels", c_int32),
+        ("clamp_max", c_float), ("norm", c_float), ("coef", c_float),
     ]
 
 
@@ -63,6 +74,7 @@ SIGNATURES = {
     "stv_relu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
     "stv_gram_partial": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "stv_gram_finish": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_void_p, c_int, c_void_p]),
+    "stv_gram_multi": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "stv_content_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "stv_content_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_void_p, c_int, c_int, c_void_p]),
     "stv_loss_combine": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]),

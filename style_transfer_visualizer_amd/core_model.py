@@ -236,6 +236,25 @@ class _Engine:
         return ops_
 
     def _forward_with_losses(self, x: torch.Tensor, *, style_coef: float, with_seed: bool) -> list:
+        # Batched loss side (default where the activations of one forward pass still fit the Infinity
+        # Cache, i.e. up to ~768^2): the whole forward pass first, then ONE batched Gram chain for all
+        # style taps (stv_gram_multi) and the content terms.  The chain is five latency-bound
+        # problems; in one grid they cost the slowest, not the sum.  Larger images keep the
+        # interleaved order (each tap right behind its producer, while its activation is cache
+        # resident).
+        s = self.sched
+        act_bytes = sum(nd.dst.act.numel() * nd.dst.act.element_size() for nd in s.nodes)
+        mode = os.environ.get("STV_LOSS_BATCH", "auto")
+        batched = (mode == "1" or (mode == "auto" and act_bytes <= 160 * 2 ** 20)) and 0 < len(s.style_taps) <= 8 \
+            and x.is_cuda
+        if batched:
+            specs = [dict(tap=tap, target=tap.target, loss_part=self.parts[tap.parts_off:],
+                          sgrad=tap.sgrad if with_seed else None, coef=style_coef) for tap in s.style_taps]
+            tail = [s.gram_multi_op(specs)]
+            for tap in s.content_taps:
+                tail += self._tap_loss_ops(tap, style_coef=style_coef, coef_dev=None, with_seed=with_seed)
+            return s.forward_ops(x) + tail
+
         def after(node):
             out = []
             for tap in node.dst.taps:

@@ -37,9 +37,8 @@ struct GramCfg {
 inline int gram_tile(int C) { return C <= 64 ? 64 : 128; }
 
 template <typename T, int TS>
-__global__ __launch_bounds__(256) void gram_partial_kernel(const T* __restrict__ F,
-                                                           float* __restrict__ partials, int N, int C,
-                                                           int ksplit, int chunk) {
+__device__ __forceinline__ void gram_partial_body(const T* __restrict__ F, float* __restrict__ partials, int N, int C,
+                                                  int ksplit, int chunk, int bx, int by) {
   using G = GramCfg<TS>;
   constexpr int kVec = elem_traits<T>::kVec;
   constexpr int VPR = TS / kVec;              // 16-byte vectors per tile row
@@ -50,11 +49,11 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(const T* __restrict__
 
   // decode upper-triangular tile pair (ti <= tj) from blockIdx.x
   const int nt = (C + TS - 1) / TS;
-  int ti = 0, rem = blockIdx.x;
+  int ti = 0, rem = bx;
   while (rem >= nt - ti) { rem -= nt - ti; ++ti; }
   const int tj = ti + rem;
   const int i0 = ti * TS, j0 = tj * TS;
-  const int ks = blockIdx.y;
+  const int ks = by;
   const int p_begin = ks * chunk;
   const int p_end = min(N, p_begin + chunk);
 
@@ -145,6 +144,36 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(const T* __restrict__
       }
 }
 
+// One batched launch covers several taps (layers): blocks [block0[i], block0[i+1]) belong to tap i.
+// The Gram chain of a step is five small, latency-bound problems; side by side in one grid they
+// take the time of the slowest instead of the sum.
+constexpr int kMaxTaps = 8;
+struct PartialMulti {
+  int n;
+  int block0[kMaxTaps + 1];
+  const void* F[kMaxTaps];
+  float* partials[kMaxTaps];
+  int N[kMaxTaps], C[kMaxTaps], ksplit[kMaxTaps], chunk[kMaxTaps], pairs[kMaxTaps];
+};
+__device__ __forceinline__ int find_tap(const int* block0, int n, int b) {
+  int i = 0;
+  while (i + 1 < n && b >= block0[i + 1]) ++i;
+  return i;
+}
+
+template <typename T, int TS>
+__global__ __launch_bounds__(256) void gram_partial_kernel(const T* __restrict__ F, float* __restrict__ partials,
+                                                           int N, int C, int ksplit, int chunk) {
+  gram_partial_body<T, TS>(F, partials, N, C, ksplit, chunk, blockIdx.x, blockIdx.y);
+}
+template <typename T, int TS>
+__global__ __launch_bounds__(256) void gram_partial_multi_kernel(PartialMulti m) {
+  const int i = find_tap(m.block0, m.n, blockIdx.x);
+  const int b = blockIdx.x - m.block0[i];
+  gram_partial_body<T, TS>(static_cast<const T*>(m.F[i]), m.partials[i], m.N[i], m.C[i], m.ksplit[i], m.chunk[i],
+                           b % m.pairs[i], b / m.pairs[i]);
+}
+
 // ---- bf16 features: v_mfma_f32_32x32x16_bf16 fed by transposing LDS reads -------------------------
 // The contraction runs over pixels while memory is pixel-major, so each MFMA operand needs, per
 // lane, 8 consecutive PIXELS of one channel.  ds_read_b64_tr_b16 delivers exactly that: a 16-lane
@@ -167,9 +196,8 @@ struct GramBCfg {
 };
 
 template <int TS>
-__global__ __launch_bounds__(256) void gram_partial_bf16_kernel(const bf16_t* __restrict__ F,
-                                                                float* __restrict__ partials, int N, int C,
-                                                                int ksplit, int chunk) {
+__device__ __forceinline__ void gram_partial_bf16_body(const bf16_t* __restrict__ F, float* __restrict__ partials,
+                                                       int N, int C, int ksplit, int chunk, int bx, int by) {
   using G = GramBCfg<TS>;
   constexpr int VPR = TS / 8;                 // 16-byte vectors per tile row
   constexpr int VECS = PKB * VPR;
@@ -178,12 +206,12 @@ __global__ __launch_bounds__(256) void gram_partial_bf16_kernel(const bf16_t* __
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int nt = (C + TS - 1) / TS;
-  int ti = 0, rem = blockIdx.x;
+  int ti = 0, rem = bx;
   while (rem >= nt - ti) { rem -= nt - ti; ++ti; }
   const int tj = ti + rem;
   const bool same = ti == tj;
   const int i0 = ti * TS, j0 = tj * TS;
-  const int ks = blockIdx.y;
+  const int ks = by;
   const int p_begin = ks * chunk;
   const int p_end = min(N, p_begin + chunk);
 
@@ -295,6 +323,19 @@ __global__ __launch_bounds__(256) void gram_partial_bf16_kernel(const bf16_t* __
       }
 }
 
+template <int TS>
+__global__ __launch_bounds__(256) void gram_partial_bf16_kernel(const bf16_t* __restrict__ F, float* __restrict__ partials,
+                                                                int N, int C, int ksplit, int chunk) {
+  gram_partial_bf16_body<TS>(F, partials, N, C, ksplit, chunk, blockIdx.x, blockIdx.y);
+}
+template <int TS>
+__global__ __launch_bounds__(256) void gram_partial_bf16_multi_kernel(PartialMulti m) {
+  const int i = find_tap(m.block0, m.n, blockIdx.x);
+  const int b = blockIdx.x - m.block0[i];
+  gram_partial_bf16_body<TS>(static_cast<const bf16_t*>(m.F[i]), m.partials[i], m.N[i], m.C[i], m.ksplit[i],
+                             m.chunk[i], b % m.pairs[i], b / m.pairs[i]);
+}
+
 // FIN_E consecutive Gram elements (one 128-byte line of every slab) per block, FIN_S ks-slices
 // each, reduced through LDS in a fixed order (deterministic).  The slab walk is pure latency
 // (each element is one dword per slab), so a block keeps FIN_S x 8 slabs of loads in flight.
@@ -302,14 +343,14 @@ __global__ __launch_bounds__(256) void gram_partial_bf16_kernel(const bf16_t* __
 // FIN_S is 32 for long slab walks (small C: hundreds of slabs) and 8 for short ones.
 constexpr int FIN_E = 32, FIN_U = 8;
 template <typename T, int FIN_S>
-__global__ __launch_bounds__(FIN_E * FIN_S) void gram_finish_kernel(
+__device__ __forceinline__ void gram_finish_body(
     const float* __restrict__ partials, const float* __restrict__ target, float* __restrict__ gram_out,
     float* __restrict__ loss_part, T* __restrict__ sgrad, int C, int TS, int ksplit, float clamp_max,
-    float norm, float k_grad, const float* __restrict__ coef_dev) {
+    float norm, float k_grad, const float* __restrict__ coef_dev, int bx) {
   __shared__ float red[FIN_S][FIN_E];
   const int le = threadIdx.x % FIN_E;
   const int slice = threadIdx.x / FIN_E;
-  const int e = blockIdx.x * FIN_E + le;
+  const int e = bx * FIN_E + le;
   const int CC = C * C;
   // Only tiles with tile(row) <= tile(col) were produced.  Elements of a lower tile have nothing
   // to read: they are finished, as mirror images, by the thread that owns the upper-tile element,
@@ -362,8 +403,37 @@ __global__ __launch_bounds__(FIN_E * FIN_S) void gram_finish_kernel(
     // FIN_E = 32 active lanes of wave 0 (lanes 32..63 belong to slice 1 and stay out)
 #pragma unroll
     for (int o = FIN_E / 2; o > 0; o >>= 1) d2 += __shfl_xor(d2, o, FIN_E);
-    if (le == 0 && loss_part) loss_part[blockIdx.x] = d2;
+    if (le == 0 && loss_part) loss_part[bx] = d2;
   }
+}
+
+template <typename T, int FIN_S>
+__global__ __launch_bounds__(FIN_E * FIN_S) void gram_finish_kernel(
+    const float* __restrict__ partials, const float* __restrict__ target, float* __restrict__ gram_out,
+    float* __restrict__ loss_part, T* __restrict__ sgrad, int C, int TS, int ksplit, float clamp_max,
+    float norm, float k_grad, const float* __restrict__ coef_dev) {
+  gram_finish_body<T, FIN_S>(partials, target, gram_out, loss_part, sgrad, C, TS, ksplit, clamp_max, norm, k_grad, coef_dev,
+                             blockIdx.x);
+}
+
+struct FinishMulti {
+  int n;
+  int block0[kMaxTaps + 1];
+  const float* partials[kMaxTaps];
+  const float* target[kMaxTaps];
+  float* gram_out[kMaxTaps];
+  float* loss_part[kMaxTaps];
+  void* sgrad[kMaxTaps];
+  const float* coef_dev[kMaxTaps];
+  int C[kMaxTaps], TS[kMaxTaps], ksplit[kMaxTaps];
+  float clamp_max[kMaxTaps], norm[kMaxTaps], k_grad[kMaxTaps];
+};
+template <typename T>
+__global__ __launch_bounds__(FIN_E * 8) void gram_finish_multi_kernel(FinishMulti m) {
+  const int i = find_tap(m.block0, m.n, blockIdx.x);
+  gram_finish_body<T, 8>(m.partials[i], m.target[i], m.gram_out[i], m.loss_part[i], static_cast<T*>(m.sgrad[i]), m.C[i],
+                         m.TS[i], m.ksplit[i], m.clamp_max[i], m.norm[i], m.k_grad[i], m.coef_dev[i],
+                         blockIdx.x - m.block0[i]);
 }
 
 template <int TS>
@@ -481,6 +551,85 @@ extern "C" int stv_gram_finish(const float* partials, const float* target, float
 #undef STV_FINISH
   else
     return STV_ERR_ARG;
+  STV_CHECK_LAUNCH();
+  return STV_OK;
+}
+
+// ---- batched Gram chain: all taps of a step in two (partial: one per tile size) + one launches ----
+extern "C" int stv_gram_multi(const stv_gram_tap_t* taps, int n_taps, int dtype, void* stream) {
+  if (!taps || n_taps <= 0 || n_taps > kMaxTaps) return STV_ERR_ARG;
+  if (dtype != STV_F32 && dtype != STV_BF16) return STV_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int vec = dtype == STV_F32 ? 4 : 8;
+  for (int i = 0; i < n_taps; ++i) {
+    const stv_gram_tap_t& t = taps[i];
+    if (!t.F || !t.partials || t.n_pixels <= 0 || t.channels <= 0 || t.channels % vec || t.norm <= 0.0f) return STV_ERR_ARG;
+    if (dtype == STV_BF16 && (size_t)t.n_pixels * t.channels * 2 >= ((size_t)1 << 31)) return STV_ERR_ARG;
+  }
+  // partial sums: one launch per tile size present
+  for (int TS : {64, 128}) {
+    PartialMulti m{};
+    for (int i = 0; i < n_taps; ++i) {
+      const stv_gram_tap_t& t = taps[i];
+      if (gram_tile(t.channels) != TS) continue;
+      const int nt = ceil_div(t.channels, TS), pairs = nt * (nt + 1) / 2;
+      const int ksplit = stv_gram_ksplit(t.n_pixels, t.channels);
+      const int pk = dtype == STV_BF16 ? PKB : PK;
+      int chunk = ceil_div(t.n_pixels, ksplit);
+      chunk = ceil_div(chunk, pk) * pk;
+      const int k = m.n++;
+      m.F[k] = t.F; m.partials[k] = t.partials; m.N[k] = t.n_pixels; m.C[k] = t.channels;
+      m.ksplit[k] = ksplit; m.chunk[k] = chunk; m.pairs[k] = pairs;
+      m.block0[k + 1] = m.block0[k] + pairs * ksplit;
+    }
+    if (!m.n) continue;
+    const dim3 grid(m.block0[m.n]);
+#define STV_SET_LDS(kern, bytes)                                                                             \
+  do {                                                                                                       \
+    static bool done = false;                                                                                \
+    if (!done) {                                                                                             \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              bytes) != hipSuccess)                                                          \
+        return STV_ERR_LAUNCH;                                                                               \
+      done = true;                                                                                           \
+    }                                                                                                        \
+  } while (0)
+    if (dtype == STV_BF16) {
+      if (TS == 64) {
+        STV_SET_LDS(gram_partial_bf16_multi_kernel<64>, GramBCfg<64>::LDS_BYTES);
+        hipLaunchKernelGGL(gram_partial_bf16_multi_kernel<64>, grid, dim3(256), GramBCfg<64>::LDS_BYTES, st, m);
+      } else {
+        STV_SET_LDS(gram_partial_bf16_multi_kernel<128>, GramBCfg<128>::LDS_BYTES);
+        hipLaunchKernelGGL(gram_partial_bf16_multi_kernel<128>, grid, dim3(256), GramBCfg<128>::LDS_BYTES, st, m);
+      }
+    } else {
+      if (TS == 64) {
+        STV_SET_LDS((gram_partial_multi_kernel<float, 64>), GramCfg<64>::LDS_BYTES);
+        hipLaunchKernelGGL((gram_partial_multi_kernel<float, 64>), grid, dim3(256), GramCfg<64>::LDS_BYTES, st, m);
+      } else {
+        STV_SET_LDS((gram_partial_multi_kernel<float, 128>), GramCfg<128>::LDS_BYTES);
+        hipLaunchKernelGGL((gram_partial_multi_kernel<float, 128>), grid, dim3(256), GramCfg<128>::LDS_BYTES, st, m);
+      }
+    }
+#undef STV_SET_LDS
+    STV_CHECK_LAUNCH();
+  }
+  // finish: one launch for every tap
+  FinishMulti f{};
+  f.n = n_taps;
+  for (int i = 0; i < n_taps; ++i) {
+    const stv_gram_tap_t& t = taps[i];
+    f.partials[i] = t.partials; f.target[i] = t.target; f.gram_out[i] = t.gram_out; f.loss_part[i] = t.loss_part;
+    f.sgrad[i] = t.sgrad; f.coef_dev[i] = t.coef_dev; f.C[i] = t.channels; f.TS[i] = gram_tile(t.channels);
+    f.ksplit[i] = stv_gram_ksplit(t.n_pixels, t.channels);
+    f.clamp_max[i] = t.clamp_max; f.norm[i] = t.norm;
+    f.k_grad[i] = t.coef * 4.0f / ((float)t.channels * (float)t.channels * t.norm);
+    f.block0[i + 1] = f.block0[i] + stv_gram_loss_parts(t.channels);
+  }
+  if (dtype == STV_F32)
+    hipLaunchKernelGGL(gram_finish_multi_kernel<float>, dim3(f.block0[n_taps]), dim3(FIN_E * 8), 0, st, f);
+  else
+    hipLaunchKernelGGL(gram_finish_multi_kernel<bf16_t>, dim3(f.block0[n_taps]), dim3(FIN_E * 8), 0, st, f);
   STV_CHECK_LAUNCH();
   return STV_OK;
 }

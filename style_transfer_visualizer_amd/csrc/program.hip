@@ -15,6 +15,8 @@ struct stv_program {
   // stream with events, so that small latency-bound chains overlap the main chain
   hipStream_t side = nullptr;
   std::vector<hipEvent_t> events;
+  // host-side tap arrays of GRAM_MULTI ops, owned here (the ops' p0 points into them)
+  std::vector<std::vector<stv_gram_tap_t>> tap_tables;
 };
 
 namespace {
@@ -70,6 +72,8 @@ int run_op(const stv_op_t& op, void* st) {
       return stv_loss_combine(static_cast<const float*>(o.p0), static_cast<const int32_t*>(o.p1),
                               static_cast<const float*>(o.p2), o.cin, o.f0, o.f1,
                               static_cast<float*>(o.q0), static_cast<float*>(o.q1), st);
+    case STV_OP_GRAM_MULTI:
+      return stv_gram_multi(static_cast<const stv_gram_tap_t*>(o.p0), (int)o.n, o.dtype, st);
     case STV_OP_MEMSET:
       if (hipMemsetAsync(o.q0, 0, (size_t)o.n, static_cast<hipStream_t>(st)) != hipSuccess)
         return STV_ERR_LAUNCH;
@@ -149,6 +153,18 @@ extern "C" int stv_program_create(const stv_op_t* ops, int n_ops, stv_program** 
   stv_program* p = new (std::nothrow) stv_program();
   if (!p) return STV_ERR_ALLOC;
   p->ops.assign(ops, ops + n_ops);
+  for (stv_op_t& o : p->ops) {
+    if (o.op != STV_OP_GRAM_MULTI) continue;
+    if (!o.p0 || o.n <= 0 || o.n > 8) {
+      delete p;
+      return STV_ERR_ARG;
+    }
+    const stv_gram_tap_t* src = static_cast<const stv_gram_tap_t*>(o.p0);
+    p->tap_tables.emplace_back(src, src + o.n);
+  }
+  size_t k = 0;                    // (pointers taken after the last emplace_back: the vectors no longer move)
+  for (stv_op_t& o : p->ops)
+    if (o.op == STV_OP_GRAM_MULTI) o.p0 = p->tap_tables[k++].data();
   *out = p;
   return STV_OK;
 }

@@ -9,6 +9,8 @@ float32 or bfloat16; the image / its gradient are ``[1, 3, H, W]`` float32.
 """
 from __future__ import annotations
 
+import ctypes
+
 import torch
 
 from . import _lib
@@ -203,6 +205,32 @@ def conv_igemm_dual(x: torch.Tensor, w: torch.Tensor, x2: torch.Tensor, w2: torc
     _lib.check(lib.stv_conv_igemm_dual(_ptr(x), _ptr(w), _ptr(x2), _ptr(w2), _ptr(ref), _ptr(out), H, W, cin, cin2,
                                        cout, flags, dtype_code(x.dtype), _stream()), "stv_conv_igemm_dual")
     return out
+
+
+def gram_multi(feats: list[torch.Tensor], targets: list[torch.Tensor], *, coef: float = 1.0,
+               clamp_max: float = 5e5) -> tuple[list[torch.Tensor], list[torch.Tensor], list[torch.Tensor]]:
+    """Batched Gram chain (stv_gram_multi) over NHWC feature maps: returns (grams, loss partials, seeds) per tap."""
+    lib = _lib.load()
+    table = (_lib.StvGramTap * len(feats))()
+    keep, grams, parts, seeds = [], [], [], []
+    for e, f, t in zip(table, feats, targets, strict=True):
+        H, W, C = f.shape
+        n = H * W
+        partials = torch.empty(gram_ksplit(n, C), C, C, device=f.device, dtype=torch.float32)
+        g = torch.empty(C, C, device=f.device, dtype=torch.float32)
+        lp = torch.empty(gram_loss_parts(C), device=f.device, dtype=torch.float32)
+        sg = torch.empty(C, C, device=f.device, dtype=f.dtype)
+        keep += [partials]
+        grams.append(g); parts.append(lp); seeds.append(sg)
+        e.F, e.partials, e.target, e.gram_out, e.loss_part, e.sgrad = (_ptr(f), _ptr(partials), _ptr(t), _ptr(g), _ptr(lp),
+                                                                      _ptr(sg))
+        e.coef_dev = None
+        e.n_pixels, e.channels = n, C
+        e.clamp_max, e.norm, e.coef = clamp_max, float(C * n), coef
+    _lib.check(lib.stv_gram_multi(ctypes.addressof(table), len(feats), dtype_code(feats[0].dtype), _stream()),
+               "stv_gram_multi")
+    torch.cuda.current_stream().synchronize()       # `partials` may go out of scope now
+    return grams, parts, seeds
 
 
 # ---- pool / relu --------------------------------------------------------------

@@ -27,7 +27,7 @@ import torch
 from torch import nn
 
 from . import _lib, ops
-from ._lib import (ACCUM, MASK, W_BLOCKED, OP_CONTENT_GRAD, OP_CONTENT_LOSS, OP_CONV, OP_CONV_FIRST_DGRAD,
+from ._lib import (ACCUM, MASK, W_BLOCKED, OP_GRAM_MULTI, OP_CONTENT_GRAD, OP_CONTENT_LOSS, OP_CONV, OP_CONV_FIRST_DGRAD,
                    OP_CONV_FIRST_FWD, OP_GRAM_FINISH, OP_GRAM_PARTIAL, OP_LOSS_COMBINE, OP_POOL_BWD,
                    OP_POOL_FWD, OP_RELU_BWD, OP_RELU_FWD, RELU_IN, RELU_OUT, StvOp)
 
@@ -258,6 +258,30 @@ class Schedule:
         out.append(self._op(op=OP_GRAM_FINISH, p0=tap.partials, p1=target, p2=coef_dev, q0=gram_out, q1=loss_part,
                             q2=sgrad, n=n, cin=b.C, f0=GRAM_CLAMP_MAX, f1=float(b.C * n), f2=coef))
         return out
+
+    def gram_multi_op(self, specs: list[dict]) -> StvOp:
+        """One batched Gram chain (stv_gram_multi) for several taps.  ``specs``: per tap the keyword
+        arguments of :meth:`gram_ops` plus ``tap``.  The tap table is a host array the program copies."""
+        table = (_lib.StvGramTap * len(specs))()
+
+        def ptr(t: torch.Tensor | None) -> int | None:
+            if t is None:
+                return None
+            self._keep.append(t)
+            return t.data_ptr()
+        for e, sp in zip(table, specs, strict=True):
+            tap = sp["tap"]
+            b = tap.buf
+            n = b.H * b.W
+            if tap.partials is None:
+                tap.partials = torch.empty(ops.gram_ksplit(n, b.C), b.C, b.C, device=self.device, dtype=torch.float32)
+            e.F, e.partials = ptr(b.act), ptr(tap.partials)
+            e.target, e.gram_out, e.loss_part = ptr(sp.get("target")), ptr(sp.get("gram_out")), ptr(sp.get("loss_part"))
+            e.sgrad, e.coef_dev = ptr(sp.get("sgrad")), ptr(sp.get("coef_dev"))
+            e.n_pixels, e.channels = n, b.C
+            e.clamp_max, e.norm, e.coef = GRAM_CLAMP_MAX, float(b.C * n), float(sp.get("coef", 0.0))
+        self._keep.append(table)                    # the host array must outlive stv_program_create
+        return self._op(op=OP_GRAM_MULTI, p0=ctypes.addressof(table), n=len(specs))
 
     def alloc_grads(self) -> None:
         for nd in self.nodes:

@@ -332,6 +332,27 @@ def test_content_loss_and_grad(dtype):
     assert_close(out, fr.grad + prev, dtype, 1, "content grad")
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gram_multi_matches_the_single_tap_calls(dtype):
+    """One batched launch pair for five taps (tile sizes 64 and 128, 1..512 slabs) = the per-tap calls."""
+    shapes = [(64, 48, 64), (32, 40, 128), (16, 24, 256), (8, 8, 512), (12, 20, 8)]
+    feats = [rnd((H, W, C), 80 + i, -1.5, 1.5).to(dtype).to(DEV) for i, (H, W, C) in enumerate(shapes)]
+    tgts = [ocm.gram_matrix(rnd((1, C, H, W), 90 + i)).to(DEV).contiguous() for i, (H, W, C) in enumerate(shapes)]
+    grams, parts, seeds = ops.gram_multi(feats, tgts, coef=3.0)
+    for f, t, g, lp, sg in zip(feats, tgts, grams, parts, seeds, strict=True):
+        H, W, C = f.shape
+        n = H * W
+        partials = ops.gram_partial(f)
+        g1 = torch.empty(C, C, device=DEV)
+        lp1 = torch.empty(ops.gram_loss_parts(C), device=DEV)
+        sg1 = torch.empty(C, C, device=DEV, dtype=dtype)
+        ops.gram_finish(partials, n, C, target=t, gram_out=g1, loss_part=lp1, sgrad=sg1, coef=3.0, dtype=dtype)
+        scale = float(g1.abs().max())
+        assert float((g - g1).abs().max()) <= 2e-6 * scale          # summation order of the slabs may differ
+        assert float(lp.sum()) == pytest.approx(float(lp1.sum()), rel=1e-5)
+        assert float((sg.float() - sg1.float()).abs().max()) <= (2e-6 if dtype == torch.float32 else 8e-3) * float(sg1.float().abs().max())
+
+
 def test_loss_combine():
     parts = torch.arange(1, 41, dtype=torch.float32, device=DEV)
     table = torch.tensor([[0, 10, 0], [10, 10, 0], [20, 20, 1]], dtype=torch.int32, device=DEV)
