@@ -47,8 +47,13 @@ class _Bar:
 
 
 def conv_flops(meta) -> float:
-    op, H, W, cin, cout, taps, _n = meta
-    return 2.0 * max(taps, 1) * cin * cout * H * W
+    """Algorithmic FLOPs of one conv op; a dgrad with the fused Gram-backward term (n = cin2 > 0 on a
+    3x3 op: stv_conv_igemm_dual) also carries that term's 1x1 product."""
+    op, H, W, cin, cout, taps, n = meta
+    flops = 2.0 * max(taps, 1) * cin * cout * H * W
+    if taps == 9 and n > 0:
+        flops += 2.0 * n * cout * H * W
+    return flops
 
 
 _CFG_NAMES = {0: "8, 128, 4, 2", 1: "8, 64, 4, 2", 2: "4, 128, 1, 4", 3: "4, 64, 2, 2", 4: "4, 64, 2, 2", 5: "8, 64, 4, 2", 6: "4, 64, 2, 2", 7: "2, 64, 2, 2"}
