@@ -393,7 +393,13 @@ __global__ __launch_bounds__(256) void conv_first_fwd_mfma(const float* __restri
 // columns of v_mfma_f32_16x16x32_bf16), K = 9 x 64.  dy is bf16 as stored; the weights are split in
 // two bf16 terms so the product stays fp32-faithful.  Only 12 lanes of a weight fragment are
 // non-zero (3 channels x 4 k-groups), so the fragment table is 7 KB of LDS.
-constexpr int DG_TH = 8, DG_TW = 32, DG_IW = DG_TW + 2, DG_PITCH = 128 + 16;
+#ifndef STV_DG_TH
+#define STV_DG_TH 8
+#endif
+constexpr int DG_TH = STV_DG_TH, DG_TW = 32, DG_IW = DG_TW + 2, DG_PITCH = 128 + 16;
+constexpr int DG_RW = DG_TH / 4;                            // output rows per wave
+constexpr int DG_MB = DG_RW * 2;                            // 16-pixel MFMA row blocks per wave
+static_assert(DG_TH % 4 == 0, "four waves split the rows");
 constexpr int DG_TILE_BYTES = (DG_TH + 2) * DG_IW * DG_PITCH;
 constexpr int DG_FRAGS = 9 * 2 * 2 * 12;                    // [tap][kstep][hi|lo][c * 4 + g], 16 bytes each
 constexpr int DG_FRAG_WORDS = DG_FRAGS * 4;
@@ -460,9 +466,9 @@ __global__ __launch_bounds__(256) void conv_first_dgrad_mfma(const bf16_t* __res
     }
     if (t + (int)gridDim.x < ntiles) request(t + gridDim.x);
     __syncthreads();
-    acc_t acc[4];
+    acc_t acc[DG_MB];
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) acc[mb] = acc_t{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int mb = 0; mb < DG_MB; ++mb) acc[mb] = acc_t{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap) {
       const int dyo = tap / 3, dxo = tap - dyo * 3;
@@ -472,8 +478,8 @@ __global__ __launch_bounds__(256) void conv_first_dgrad_mfma(const bf16_t* __res
         const bf16x8v b_hi = __builtin_bit_cast(bf16x8v, wtab[ent >= 0 ? fb + ent : DG_FRAGS]);
         const bf16x8v b_lo = __builtin_bit_cast(bf16x8v, wtab[ent >= 0 ? fb + 12 + ent : DG_FRAGS]);
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
-          const int row = wave * 2 + (mb >> 1) + dyo, col = (mb & 1) * 16 + r + dxo;
+        for (int mb = 0; mb < DG_MB; ++mb) {
+          const int row = wave * DG_RW + (mb >> 1) + dyo, col = (mb & 1) * 16 + r + dxo;
           const bf16x8v a = __builtin_bit_cast(
               bf16x8v, *reinterpret_cast<const u32x4*>(tile + (row * DG_IW + col) * DG_PITCH + ks * 64 + g * 16));
           acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b_lo, acc[mb], 0, 0, 0);
@@ -484,8 +490,8 @@ __global__ __launch_bounds__(256) void conv_first_dgrad_mfma(const bf16_t* __res
     // D: column (lane & 15) = channel, rows 4g..4g+3 = pixels of the 16-pixel block
     if (r < 3) {
 #pragma unroll
-      for (int mb = 0; mb < 4; ++mb) {
-        const int gy = y0 + wave * 2 + (mb >> 1);
+      for (int mb = 0; mb < DG_MB; ++mb) {
+        const int gy = y0 + wave * DG_RW + (mb >> 1);
         if (gy >= H) continue;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -608,7 +614,8 @@ int dgrad_typed(const void* dy, const float* wf, const float* packed, float* dx,
   if (cin == 3 && cout == 64 && packed && std::is_same<T, bf16_t>::value && !getenv("STV_FIRST_VALU")) {
     const int tiles = ceil_div(W, DG_TW) * ceil_div(H, DG_TH);
     constexpr int lds = DG_TILE_BYTES + (DG_FRAGS + 1) * 16;
-    const int grid = tiles < 2 * 256 ? tiles : 2 * 256;       // two resident workgroups per CU walk the tiles
+    static const int dg_wgs = getenv("STV_FIRST_DG_WGS") ? atoi(getenv("STV_FIRST_DG_WGS")) : 2;
+    const int grid = tiles < dg_wgs * 256 ? tiles : dg_wgs * 256;   // resident workgroups walk the tiles
     hipLaunchKernelGGL(conv_first_dgrad_mfma, dim3(grid), dim3(256), lds, st, static_cast<const bf16_t*>(dy),
                        reinterpret_cast<const uint32_t*>(packed + 2 * 1728 + MF_FRAG_WORDS), dx, H, W);
     STV_CHECK_LAUNCH();
