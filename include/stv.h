@@ -162,11 +162,10 @@ int stv_gram_finish(const float* partials, const float* target, float* gram_out,
                     float norm, float coef, const float* coef_dev, int dtype, void* stream);
 
 /* The Gram chain of several taps (layers) in one call: one batched stv_gram_partial launch per
- * tile size present plus one batched stv_gram_finish launch, instead of two launches per tap.
+ * tile size present plus one batched stv_gram_finish launch per slab-depth class, instead of two launches per tap.
  * The chain of a step is five small latency-bound problems; side by side in one grid they cost
  * the slowest, not the sum.  Fields as the arguments of the two calls above; at most 8 taps.
- * (The finish of a tap with hundreds of slabs sums them in a different - still fixed - order
- * than stv_gram_finish: results agree to fp32 rounding.) */
+ * Same arithmetic, same fixed summation order as the per-tap calls. */
 typedef struct {
   const void* F;          /* features, NHWC [n_pixels][channels] in `dtype` */
   float* partials;        /* stv_gram_partials_bytes(n_pixels, channels) */

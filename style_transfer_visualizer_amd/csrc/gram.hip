@@ -184,7 +184,10 @@ __global__ __launch_bounds__(256) void gram_partial_multi_kernel(PartialMulti m)
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-constexpr int PKB = 64;   // pixels per LDS stage (bf16 path)
+#ifndef STV_GRAM_PKB
+#define STV_GRAM_PKB 64
+#endif
+constexpr int PKB = STV_GRAM_PKB;   // pixels per LDS stage (bf16 path)
 
 template <int TS>
 struct GramBCfg {
@@ -428,10 +431,10 @@ struct FinishMulti {
   int C[kMaxTaps], TS[kMaxTaps], ksplit[kMaxTaps];
   float clamp_max[kMaxTaps], norm[kMaxTaps], k_grad[kMaxTaps];
 };
-template <typename T>
-__global__ __launch_bounds__(FIN_E * 8) void gram_finish_multi_kernel(FinishMulti m) {
+template <typename T, int FIN_S>
+__global__ __launch_bounds__(FIN_E * FIN_S) void gram_finish_multi_kernel(FinishMulti m) {
   const int i = find_tap(m.block0, m.n, blockIdx.x);
-  gram_finish_body<T, 8>(m.partials[i], m.target[i], m.gram_out[i], m.loss_part[i], static_cast<T*>(m.sgrad[i]), m.C[i],
+  gram_finish_body<T, FIN_S>(m.partials[i], m.target[i], m.gram_out[i], m.loss_part[i], static_cast<T*>(m.sgrad[i]), m.C[i],
                          m.TS[i], m.ksplit[i], m.clamp_max[i], m.norm[i], m.k_grad[i], m.coef_dev[i],
                          blockIdx.x - m.block0[i]);
 }
@@ -614,22 +617,32 @@ extern "C" int stv_gram_multi(const stv_gram_tap_t* taps, int n_taps, int dtype,
 #undef STV_SET_LDS
     STV_CHECK_LAUNCH();
   }
-  // finish: one launch for every tap
-  FinishMulti f{};
-  f.n = n_taps;
-  for (int i = 0; i < n_taps; ++i) {
-    const stv_gram_tap_t& t = taps[i];
-    f.partials[i] = t.partials; f.target[i] = t.target; f.gram_out[i] = t.gram_out; f.loss_part[i] = t.loss_part;
-    f.sgrad[i] = t.sgrad; f.coef_dev[i] = t.coef_dev; f.C[i] = t.channels; f.TS[i] = gram_tile(t.channels);
-    f.ksplit[i] = stv_gram_ksplit(t.n_pixels, t.channels);
-    f.clamp_max[i] = t.clamp_max; f.norm[i] = t.norm;
-    f.k_grad[i] = t.coef * 4.0f / ((float)t.channels * (float)t.channels * t.norm);
-    f.block0[i + 1] = f.block0[i] + stv_gram_loss_parts(t.channels);
+  // finish: one launch per depth class - taps with hundreds of slabs walk them with 32 slices per
+  // element (1024-thread blocks), the others with 8
+  for (int deep = 0; deep < 2; ++deep) {
+    FinishMulti f{};
+    for (int i = 0; i < n_taps; ++i) {
+      const stv_gram_tap_t& t = taps[i];
+      const int ksplit = stv_gram_ksplit(t.n_pixels, t.channels);
+      if ((ksplit >= 128 ? 1 : 0) != deep) continue;
+      const int k = f.n++;
+      f.partials[k] = t.partials; f.target[k] = t.target; f.gram_out[k] = t.gram_out; f.loss_part[k] = t.loss_part;
+      f.sgrad[k] = t.sgrad; f.coef_dev[k] = t.coef_dev; f.C[k] = t.channels; f.TS[k] = gram_tile(t.channels);
+      f.ksplit[k] = ksplit;
+      f.clamp_max[k] = t.clamp_max; f.norm[k] = t.norm;
+      f.k_grad[k] = t.coef * 4.0f / ((float)t.channels * (float)t.channels * t.norm);
+      f.block0[k + 1] = f.block0[k] + stv_gram_loss_parts(t.channels);
+    }
+    if (!f.n) continue;
+    const dim3 grid(f.block0[f.n]);
+    if (dtype == STV_F32) {
+      if (deep) hipLaunchKernelGGL((gram_finish_multi_kernel<float, 32>), grid, dim3(FIN_E * 32), 0, st, f);
+      else hipLaunchKernelGGL((gram_finish_multi_kernel<float, 8>), grid, dim3(FIN_E * 8), 0, st, f);
+    } else {
+      if (deep) hipLaunchKernelGGL((gram_finish_multi_kernel<bf16_t, 32>), grid, dim3(FIN_E * 32), 0, st, f);
+      else hipLaunchKernelGGL((gram_finish_multi_kernel<bf16_t, 8>), grid, dim3(FIN_E * 8), 0, st, f);
+    }
+    STV_CHECK_LAUNCH();
   }
-  if (dtype == STV_F32)
-    hipLaunchKernelGGL(gram_finish_multi_kernel<float>, dim3(f.block0[n_taps]), dim3(FIN_E * 8), 0, st, f);
-  else
-    hipLaunchKernelGGL(gram_finish_multi_kernel<bf16_t>, dim3(f.block0[n_taps]), dim3(FIN_E * 8), 0, st, f);
-  STV_CHECK_LAUNCH();
   return STV_OK;
 }
