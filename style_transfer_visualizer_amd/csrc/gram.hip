@@ -161,17 +161,26 @@ __device__ __forceinline__ int find_tap(const int* block0, int n, int b) {
   return i;
 }
 
+__device__ __forceinline__ void decode_block(int b, int pairs, int ksplit, int& pair, int& ks) {
+  pair = b % pairs;
+  ks = b / pairs;
+}
+
 template <typename T, int TS>
 __global__ __launch_bounds__(256) void gram_partial_kernel(const T* __restrict__ F, float* __restrict__ partials,
-                                                           int N, int C, int ksplit, int chunk) {
-  gram_partial_body<T, TS>(F, partials, N, C, ksplit, chunk, blockIdx.x, blockIdx.y);
+                                                           int N, int C, int ksplit, int chunk, int pairs) {
+  int pair, ks;
+  decode_block(blockIdx.x, pairs, ksplit, pair, ks);
+  gram_partial_body<T, TS>(F, partials, N, C, ksplit, chunk, pair, ks);
 }
 template <typename T, int TS>
 __global__ __launch_bounds__(256) void gram_partial_multi_kernel(PartialMulti m) {
   const int i = find_tap(m.block0, m.n, blockIdx.x);
   const int b = blockIdx.x - m.block0[i];
+  int pair, ks;
+  decode_block(b, m.pairs[i], m.ksplit[i], pair, ks);
   gram_partial_body<T, TS>(static_cast<const T*>(m.F[i]), m.partials[i], m.N[i], m.C[i], m.ksplit[i], m.chunk[i],
-                           b % m.pairs[i], b / m.pairs[i]);
+                           pair, ks);
 }
 
 // ---- bf16 features: v_mfma_f32_32x32x16_bf16 fed by transposing LDS reads -------------------------
@@ -328,32 +337,36 @@ __device__ __forceinline__ void gram_partial_bf16_body(const bf16_t* __restrict_
 
 template <int TS>
 __global__ __launch_bounds__(256) void gram_partial_bf16_kernel(const bf16_t* __restrict__ F, float* __restrict__ partials,
-                                                                int N, int C, int ksplit, int chunk) {
-  gram_partial_bf16_body<TS>(F, partials, N, C, ksplit, chunk, blockIdx.x, blockIdx.y);
+                                                                int N, int C, int ksplit, int chunk, int pairs) {
+  int pair, ks;
+  decode_block(blockIdx.x, pairs, ksplit, pair, ks);
+  gram_partial_bf16_body<TS>(F, partials, N, C, ksplit, chunk, pair, ks);
 }
 template <int TS>
 __global__ __launch_bounds__(256) void gram_partial_bf16_multi_kernel(PartialMulti m) {
   const int i = find_tap(m.block0, m.n, blockIdx.x);
   const int b = blockIdx.x - m.block0[i];
+  int pair, ks;
+  decode_block(b, m.pairs[i], m.ksplit[i], pair, ks);
   gram_partial_bf16_body<TS>(static_cast<const bf16_t*>(m.F[i]), m.partials[i], m.N[i], m.C[i], m.ksplit[i],
-                             m.chunk[i], b % m.pairs[i], b / m.pairs[i]);
+                             m.chunk[i], pair, ks);
 }
 
-// FIN_E consecutive Gram elements (one 128-byte line of every slab) per block, FIN_S ks-slices
-// each, reduced through LDS in a fixed order (deterministic).  The slab walk is pure latency
-// (each element is one dword per slab), so a block keeps FIN_S x 8 slabs of loads in flight.
-// loss_part gets one partial per block.
+// FIN_E consecutive Gram elements (512 bytes of every slab) per block: 32 lanes x one float4 each,
+// FIN_S ks-slices per element group, reduced through LDS in a fixed order (deterministic).  The
+// slab walk is latency- and dispatch-bound (a thread's whole job is a handful of loads), hence
+// 16-byte loads and FIN_S x FIN_U slabs in flight per block.  loss_part gets one partial per block.
 // FIN_S is 32 for long slab walks (small C: hundreds of slabs) and 8 for short ones.
-constexpr int FIN_E = 32, FIN_U = 8;
+constexpr int FIN_V = 4, FIN_L = 32, FIN_E = FIN_L * FIN_V, FIN_U = 4;
 template <typename T, int FIN_S>
 __device__ __forceinline__ void gram_finish_body(
     const float* __restrict__ partials, const float* __restrict__ target, float* __restrict__ gram_out,
     float* __restrict__ loss_part, T* __restrict__ sgrad, int C, int TS, int ksplit, float clamp_max,
     float norm, float k_grad, const float* __restrict__ coef_dev, int bx) {
-  __shared__ float red[FIN_S][FIN_E];
-  const int le = threadIdx.x % FIN_E;
-  const int slice = threadIdx.x / FIN_E;
-  const int e = bx * FIN_E + le;
+  __shared__ f32x4 red[FIN_S][FIN_L];
+  const int le = threadIdx.x % FIN_L;
+  const int slice = threadIdx.x / FIN_L;
+  const int e = bx * FIN_E + le * FIN_V;       // first of this thread's 4 elements (same row: C % 4 == 0)
   const int CC = C * C;
   // Only tiles with tile(row) <= tile(col) were produced.  Elements of a lower tile have nothing
   // to read: they are finished, as mirror images, by the thread that owns the upper-tile element,
@@ -362,56 +375,68 @@ __device__ __forceinline__ void gram_finish_body(
   const int i = e / C, j = e - i * C;
   const bool lower = (i / TS) > (j / TS);
   const bool mirror = (i / TS) < (j / TS);
-  float s = 0.0f;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 s = zero;
   if (e < CC && !lower) {
-    float acc[FIN_U];
+    f32x4 acc[FIN_U];
 #pragma unroll
-    for (int u = 0; u < FIN_U; ++u) acc[u] = 0.0f;
+    for (int u = 0; u < FIN_U; ++u) acc[u] = zero;
+    const float* src = partials + e;
     int ks = slice;
     for (; ks + (FIN_U - 1) * FIN_S < ksplit; ks += FIN_U * FIN_S) {
 #pragma unroll
-      for (int u = 0; u < FIN_U; ++u) acc[u] += partials[(size_t)(ks + u * FIN_S) * CC + e];
+      for (int u = 0; u < FIN_U; ++u)
+        acc[u] += *reinterpret_cast<const f32x4*>(src + (size_t)(ks + u * FIN_S) * CC);
     }
 #pragma unroll
     for (int u = 0; u < FIN_U; ++u)
-      if (ks + u * FIN_S < ksplit) acc[u] += partials[(size_t)(ks + u * FIN_S) * CC + e];
-    s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+      if (ks + u * FIN_S < ksplit) acc[u] += *reinterpret_cast<const f32x4*>(src + (size_t)(ks + u * FIN_S) * CC);
+    s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
   }
   red[slice][le] = s;
   __syncthreads();
   if (slice == 0) {
     float d2 = 0.0f;
     if (e < CC && !lower) {
-      float R = 0.0f;
+      f32x4 R = zero;
 #pragma unroll
       for (int q = 0; q < FIN_S; ++q) R += red[q][le];
-      const float Gv = fminf(R, clamp_max) / norm;
       const float kk = (target && sgrad) ? k_grad * (coef_dev ? *coef_dev : 1.0f) : 0.0f;
-      const int em = j * C + i;                       // mirror image (strictly upper tiles only)
-      if (gram_out) {
-        gram_out[e] = Gv;
-        if (mirror) gram_out[em] = Gv;
-      }
+      f32x4 Gv, tv = zero;
+#pragma unroll
+      for (int v = 0; v < FIN_V; ++v) Gv[v] = fminf(R[v], clamp_max) / norm;
+      if (gram_out) *reinterpret_cast<f32x4*>(gram_out + e) = Gv;
       if (target) {
-        const float d = Gv - target[e];
-        d2 = d * d;
-        if (sgrad) elem_traits<T>::store(sgrad + e, (R <= clamp_max) ? kk * d : 0.0f);
-        if (mirror) {
-          const float dm = Gv - target[em];
-          d2 += dm * dm;
-          if (sgrad) elem_traits<T>::store(sgrad + em, (R <= clamp_max) ? kk * dm : 0.0f);
+        tv = *reinterpret_cast<const f32x4*>(target + e);
+#pragma unroll
+        for (int v = 0; v < FIN_V; ++v) {
+          const float d = Gv[v] - tv[v];
+          d2 += d * d;
+          if (sgrad) elem_traits<T>::store(sgrad + e + v, (R[v] <= clamp_max) ? kk * d : 0.0f);
+        }
+      }
+      if (mirror) {
+#pragma unroll
+        for (int v = 0; v < FIN_V; ++v) {
+          const int em = (j + v) * C + i;               // mirror image (strictly upper tiles only)
+          if (gram_out) gram_out[em] = Gv[v];
+          if (target) {
+            const float dm = Gv[v] - target[em];
+            d2 += dm * dm;
+            if (sgrad) elem_traits<T>::store(sgrad + em, (R[v] <= clamp_max) ? kk * dm : 0.0f);
+          }
         }
       }
     }
-    // FIN_E = 32 active lanes of wave 0 (lanes 32..63 belong to slice 1 and stay out)
+    // FIN_L = 32 active lanes of wave 0 (lanes 32..63 belong to slice 1 and stay out)
 #pragma unroll
-    for (int o = FIN_E / 2; o > 0; o >>= 1) d2 += __shfl_xor(d2, o, FIN_E);
+    for (int o = FIN_L / 2; o > 0; o >>= 1) d2 += __shfl_xor(d2, o, FIN_L);
     if (le == 0 && loss_part) loss_part[bx] = d2;
   }
 }
 
 template <typename T, int FIN_S>
-__global__ __launch_bounds__(FIN_E * FIN_S) void gram_finish_kernel(
+__global__ __launch_bounds__(FIN_L * FIN_S) void gram_finish_kernel(
     const float* __restrict__ partials, const float* __restrict__ target, float* __restrict__ gram_out,
     float* __restrict__ loss_part, T* __restrict__ sgrad, int C, int TS, int ksplit, float clamp_max,
     float norm, float k_grad, const float* __restrict__ coef_dev) {
@@ -432,7 +457,7 @@ struct FinishMulti {
   float clamp_max[kMaxTaps], norm[kMaxTaps], k_grad[kMaxTaps];
 };
 template <typename T, int FIN_S>
-__global__ __launch_bounds__(FIN_E * FIN_S) void gram_finish_multi_kernel(FinishMulti m) {
+__global__ __launch_bounds__(FIN_L * FIN_S) void gram_finish_multi_kernel(FinishMulti m) {
   const int i = find_tap(m.block0, m.n, blockIdx.x);
   gram_finish_body<T, FIN_S>(m.partials[i], m.target[i], m.gram_out[i], m.loss_part[i], static_cast<T*>(m.sgrad[i]), m.C[i],
                          m.TS[i], m.ksplit[i], m.clamp_max[i], m.norm[i], m.k_grad[i], m.coef_dev[i],
@@ -450,8 +475,8 @@ int launch_bf16(const bf16_t* F, float* partials, int N, int C, int pairs, int k
       return STV_ERR_LAUNCH;
     attr = true;
   }
-  hipLaunchKernelGGL((gram_partial_bf16_kernel<TS>), dim3(pairs, ksplit), dim3(256), GramBCfg<TS>::LDS_BYTES, st,
-                     F, partials, N, C, ksplit, chunk);
+  hipLaunchKernelGGL((gram_partial_bf16_kernel<TS>), dim3(pairs * ksplit), dim3(256), GramBCfg<TS>::LDS_BYTES, st,
+                     F, partials, N, C, ksplit, chunk, pairs);
   STV_CHECK_LAUNCH();
   return STV_OK;
 }
@@ -469,10 +494,10 @@ int partial_typed(const void* F, float* partials, int N, int C, hipStream_t st) 
   }
   int chunk = ceil_div(N, ksplit);
   chunk = ceil_div(chunk, PK) * PK;
-  dim3 grid(pairs, ksplit);
+  dim3 grid(pairs * ksplit);
   if (TS == 64) {
     hipLaunchKernelGGL((gram_partial_kernel<T, 64>), grid, dim3(256), GramCfg<64>::LDS_BYTES, st,
-                       static_cast<const T*>(F), partials, N, C, ksplit, chunk);
+                       static_cast<const T*>(F), partials, N, C, ksplit, chunk, pairs);
   } else {
     static bool attr = false;
     if (!attr) {
@@ -483,7 +508,7 @@ int partial_typed(const void* F, float* partials, int N, int C, hipStream_t st) 
       attr = true;
     }
     hipLaunchKernelGGL((gram_partial_kernel<T, 128>), grid, dim3(256), GramCfg<128>::LDS_BYTES, st,
-                       static_cast<const T*>(F), partials, N, C, ksplit, chunk);
+                       static_cast<const T*>(F), partials, N, C, ksplit, chunk, pairs);
   }
   STV_CHECK_LAUNCH();
   return STV_OK;
@@ -500,7 +525,8 @@ extern "C" int stv_gram_ksplit(int n_pixels, int channels) {
   static const int wg_max = getenv("STV_GRAM_WGS") ? atoi(getenv("STV_GRAM_WGS")) : 512;     // tuning aid
   static const int wg_min = getenv("STV_GRAM_WGS_MIN") ? atoi(getenv("STV_GRAM_WGS_MIN")) : 128;
   const int lo = ceil_div(wg_min, pairs), hi = (wg_max / pairs) > 0 ? wg_max / pairs : 1;
-  int ks = n_pixels / (2 * channels);
+  static const int kdiv = getenv("STV_GRAM_KDIV") ? atoi(getenv("STV_GRAM_KDIV")) : 2;
+  int ks = n_pixels / (kdiv * channels);
   if (ks < lo) ks = lo;
   if (ks > hi) ks = hi;
   const int max_ks = ceil_div(n_pixels, 64);
@@ -542,7 +568,7 @@ extern "C" int stv_gram_finish(const float* partials, const float* target, float
   const float k_grad = coef * 4.0f / ((float)C * (float)C * norm);
   const bool deep = ksplit >= 128;
 #define STV_FINISH(T, S)                                                                                     \
-  hipLaunchKernelGGL((gram_finish_kernel<T, S>), dim3(blocks), dim3(FIN_E * S), 0, st, partials, target,    \
+  hipLaunchKernelGGL((gram_finish_kernel<T, S>), dim3(blocks), dim3(FIN_L * S), 0, st, partials, target,    \
                      gram_out, loss_part, static_cast<T*>(sgrad), C, TS, ksplit, clamp_max, norm, k_grad, coef_dev)
   if (dtype == STV_F32) {
     if (deep) STV_FINISH(float, 32);
@@ -636,11 +662,11 @@ extern "C" int stv_gram_multi(const stv_gram_tap_t* taps, int n_taps, int dtype,
     if (!f.n) continue;
     const dim3 grid(f.block0[f.n]);
     if (dtype == STV_F32) {
-      if (deep) hipLaunchKernelGGL((gram_finish_multi_kernel<float, 32>), grid, dim3(FIN_E * 32), 0, st, f);
-      else hipLaunchKernelGGL((gram_finish_multi_kernel<float, 8>), grid, dim3(FIN_E * 8), 0, st, f);
+      if (deep) hipLaunchKernelGGL((gram_finish_multi_kernel<float, 32>), grid, dim3(FIN_L * 32), 0, st, f);
+      else hipLaunchKernelGGL((gram_finish_multi_kernel<float, 8>), grid, dim3(FIN_L * 8), 0, st, f);
     } else {
-      if (deep) hipLaunchKernelGGL((gram_finish_multi_kernel<bf16_t, 32>), grid, dim3(FIN_E * 32), 0, st, f);
-      else hipLaunchKernelGGL((gram_finish_multi_kernel<bf16_t, 8>), grid, dim3(FIN_E * 8), 0, st, f);
+      if (deep) hipLaunchKernelGGL((gram_finish_multi_kernel<bf16_t, 32>), grid, dim3(FIN_L * 32), 0, st, f);
+      else hipLaunchKernelGGL((gram_finish_multi_kernel<bf16_t, 8>), grid, dim3(FIN_L * 8), 0, st, f);
     }
     STV_CHECK_LAUNCH();
   }
