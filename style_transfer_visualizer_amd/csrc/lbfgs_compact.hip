@@ -17,6 +17,10 @@
 //            coefficients (in double) and emits d = cg*g + sum cs_j s_j + cy_j y_j;
 //   pass B : second sweep forms d, applies x += t*d and prev_g = g.
 // HBM traffic per step: (4m + 8) vectors instead of ~(8m) with 2m+4 launches.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "stv_common.h"
 
 namespace {
@@ -47,6 +51,8 @@ struct CWs {
 __host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 inline int tile_floats(size_t n) {   // elements per workgroup tile: >= 256 workgroups, as fat as possible
+  static const int forced = getenv("STV_LBFGS_TILE") ? atoi(getenv("STV_LBFGS_TILE")) : 0;   // tuning aid
+  if (forced == 1024 || forced == 2048 || forced == 4096) return forced;
   if (n >= (size_t)4096 * 256) return 4096;   // (the per-vector wave reductions amortise over the tile)
   if (n >= (size_t)2048 * 256) return 2048;
   return 1024;
@@ -133,7 +139,9 @@ __global__ __launch_bounds__(256) void pass_a_kernel(const float* __restrict__ g
       a3 += dot4(y4, sv[u]);   // y_j . s_c
       a4 += dot4(y4, yv[u]);   // y_j . y_c
     }
-    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3); a4 = wave_sum(a4);
+    // DPP reductions: with ds_bpermute butterflies the 5 x 6 LDS round trips per pair were 6 % of
+    // the sweep at 1024^2
+    a0 = wave_sum_dpp(a0); a1 = wave_sum_dpp(a1); a2 = wave_sum_dpp(a2); a3 = wave_sum_dpp(a3); a4 = wave_sum_dpp(a4);
     if (lane == 0) {
       float* o = w.part + (size_t)(jj * 5) * nparts + p;
       o[0] = a0; o[(size_t)nparts] = a1; o[(size_t)2 * nparts] = a2; o[(size_t)3 * nparts] = a3;
@@ -175,6 +183,15 @@ __global__ __launch_bounds__(256) void reduce_kernel(const CState* st, CWs w, in
 }
 
 // ---- control flow + recursion on coefficients ---------------------------------------------------
+// Diagnostic build (-DSTV_SOLVE_STAMPS): thread 0 leaves 100 MHz wall-clock stamps at the phase
+// boundaries of the solve kernel; tools/solve_stamps.py reads them back.
+#ifdef STV_SOLVE_STAMPS
+__device__ unsigned long long g_solve_stamps[8];
+#define SOLVE_STAMP(k) do { if (threadIdx.x == 0) g_solve_stamps[k] = wall_clock64(); } while (0)
+#else
+#define SOLVE_STAMP(k) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(256) void solve_kernel(CState* st, CWs w, int hist, float lr, float tol_grad,
                                                     float tol_change) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -191,6 +208,7 @@ __global__ __launch_bounds__(256) void solve_kernel(CState* st, CWs w, int hist,
   const double* D = w.dots;
   const double* SC = w.dots + 5 * MAX_HIST;
   const double gmax = SC[0], gl1 = SC[1], gg = SC[2], gsc = SC[3], gyc = SC[4], ys = SC[5], yy = SC[6];
+  SOLVE_STAMP(0);
 
   if (tid == 0) {
     // the 64-byte header is read and written once as a block: a chain of dependent global
@@ -241,6 +259,7 @@ __global__ __launch_bounds__(256) void solve_kernel(CState* st, CWs w, int hist,
     *reinterpret_cast<Hdr*>(st) = h;
   }
   __syncthreads();
+  SOLVE_STAMP(1);
   if (sh_skip) return;
   const int m = sh_m, head = sh_head, cslot = sh_cslot, m_old = sh_mold;
   const int old_head = (sh_pushed && m_old == hist) ? (head + S - 1) % S : head;
@@ -275,24 +294,42 @@ __global__ __launch_bounds__(256) void solve_kernel(CState* st, CWs w, int hist,
   }
   __threadfence_block();
   __syncthreads();
+  SOLVE_STAMP(2);
   {
-    // table fill: thread = (row parity, column); eight rows of loads in flight per thread - walking
-    // the rows one load at a time made this fill, not the recursion, the longest part of the kernel
+    // table fill: thread = (row parity, column), sixteen rows of loads in flight per thread (walking
+    // the rows one load at a time made this fill, not the recursion, the longest part of the kernel).
+    // The recursion only ever uses SY entries with row < column (s_i.y_j of an OLDER s with a NEWER
+    // y), so the rest of sSY is stored as zero and the walks below need no per-entry guards.
     const int j = tid & 127, i0 = tid >> 7;
     if (j < m) {
       int col = head + j;
       if (col >= S) col -= S;
-#pragma unroll 8
-      for (int i = i0; i < m; i += 2) {
-        int rs = head + i;
-        if (rs >= S) rs -= S;
-        const size_t src = (size_t)rs * S + col;
-        sSY[i * P + j] = w.SY[src];
-        sYY[i * P + j] = w.YY[src];
+      constexpr int FB = 50;                   // rows per batch: 2 x FB loads in flight, then the stores
+      for (int ib = i0; ib < m; ib += 2 * FB) {
+        float vs[FB], vy[FB];
+#pragma unroll
+        for (int k = 0; k < FB; ++k) {
+          int i = ib + 2 * k;
+          if (i >= m) i = m - 1;               // clamped, not branched: keeps the batch one burst of loads
+          int rs = head + i;
+          if (rs >= S) rs -= S;
+          const size_t src = (size_t)rs * S + col;
+          vs[k] = w.SY[src];
+          vy[k] = w.YY[src];
+        }
+#pragma unroll
+        for (int k = 0; k < FB; ++k) {
+          const int i = ib + 2 * k;
+          if (i < m) {
+            sSY[i * P + j] = (i < j) ? vs[k] : 0.0f;
+            sYY[i * P + j] = vy[k];
+          }
+        }
       }
     }
   }
   __syncthreads();
+  SOLVE_STAMP(3);
   if (tid >= 64) return;
 
   // ---- one wave: torch's two-loop on coefficients; lane owns logical indices lane, lane+64 ----
@@ -316,98 +353,127 @@ __global__ __launch_bounds__(256) void solve_kernel(CState* st, CWs w, int hist,
   double cg = -1.0;
   // The three walks are serial in i; what each step needs from LDS does not depend on the chain,
   // so it is fetched four steps ahead (CH values per owned index) while the previous four run.
+  // Each walk is split at index 64 (owner slot 0 / slot 1 of a lane) into two instantiations: with
+  // the slot a compile-time constant a step is ~25 instructions; with run-time selects it was ~65,
+  // and the kernel is bound by exactly that instruction count (one wave, one serial chain).
   constexpr int CH = 4;
-  {
+  using hi_t = std::integral_constant<bool, true>;
+  using lo_t = std::integral_constant<bool, false>;
+  const int r0 = (j0 < m ? j0 : m - 1) * P, r1 = (j1 < m ? j1 : m - 1) * P;   // row bases (clamped: unused lanes)
+  const int q0 = j0 < m ? j0 : m - 1, q1 = j1 < m ? j1 : m - 1;               // column indices, same clamp
+  const float ro0f = (float)ro0, ro1f = (float)ro1;
+  // walk 1, i = m-1 .. 0:  al_i = ro_i * (cg*(g.s_i) + a_i),  a_own -= al_i * SY[own][i]
+  auto walk1 = [&](auto HI, int ifrom, int ito) {
+    constexpr bool hi = decltype(HI)::value;
+    if (ifrom < ito) return;
     float n0[CH], n1[CH];
-    auto fetch = [&](int ib) {                 // column entries SY[own][ib - k]
+    auto fetch = [&](int ib) {                 // column entries SY[own][ib - k] (zero unless own < i)
 #pragma unroll
       for (int k = 0; k < CH; ++k) {
-        const int i = ib - k;
-        n0[k] = (i >= 0 && j0 < i) ? sSY[j0 * P + i] : 0.0f;
-        n1[k] = (i >= 0 && j1 < i) ? sSY[j1 * P + i] : 0.0f;
+        const int i = max(ib - k, 0);
+        n0[k] = sSY[r0 + i];
+        if (hi) n1[k] = sSY[r1 + i];           // below 64 no slot-1 index is older than i
       }
     };
-    fetch(m - 1);
-    for (int ib = m - 1; ib >= 0; ib -= CH) {
+    fetch(ifrom);
+    for (int ib = ifrom; ib >= ito; ib -= CH) {
       float c0[CH], c1[CH];
 #pragma unroll
-      for (int k = 0; k < CH; ++k) { c0[k] = n0[k]; c1[k] = n1[k]; }
-      if (ib - CH >= 0) fetch(ib - CH);
+      for (int k = 0; k < CH; ++k) { c0[k] = n0[k]; c1[k] = hi ? n1[k] : 0.0f; }
+      if (ib - CH >= ito) fetch(ib - CH);
 #pragma unroll
       for (int k = 0; k < CH; ++k) {
         const int i = ib - k;
-        if (i < 0) break;
-        const bool hi = i >= 64;               // wave-uniform: which owned slot holds index i
-        const double cand = (double)(float)((float)(cg * (hi ? gs1 : gs0) + (hi ? a1 : a0)) * (float)(hi ? ro1 : ro0));
-        const double al = bcast(cand, i & 63); // fp32-rounded like torch's al[i]
-        if (i == j0) { al0 = al; cy0 = -al; }
-        if (i == j1) { al1 = al; cy1 = -al; }
-        a0 -= al * (double)c0[k];              // entries outside j < i were fetched as zero
-        a1 -= al * (double)c1[k];
+        if (i < ito) break;
+        const int src = hi ? i - 64 : i;       // wave-uniform owner lane
+        const double cand = (double)(float)((float)(cg * (hi ? gs1 : gs0) + (hi ? a1 : a0)) * (hi ? ro1f : ro0f));
+        const double al = bcast(cand, src);    // fp32-rounded like torch's al[i]
+        if (lane == src) {
+          if (hi) { al1 = al; cy1 = -al; } else { al0 = al; cy0 = -al; }
+        }
+        a0 -= al * (double)c0[k];
+        if (hi) a1 -= al * (double)c1[k];
       }
     }
+  };
+  if (m > 0) {
+    walk1(hi_t{}, m - 1, 64);
+    walk1(lo_t{}, m - 1 < 63 ? m - 1 : 63, 0);
   }
+  SOLVE_STAMP(4);
   const double H = (double)sh_H;
   cg *= H; cy0 *= H; cy1 *= H;
-  // b_own = cg*(g.y_own) + sum_j cy_j * YY[own][j]  (no recursion: cy is final)
+  // walk 2: b_own = cg*(g.y_own) + sum_j cy_j * YY[own][j]  (no recursion: cy is final)
   double b0 = cg * gy0, b1 = cg * gy1;
-  {
+  auto walk2 = [&](auto HI, int jfrom, int jto) {       // j = jfrom .. jto-1
+    constexpr bool hi = decltype(HI)::value;
+    if (jfrom >= jto) return;
     float n0[CH], n1[CH];
     auto fetch = [&](int jb) {
 #pragma unroll
       for (int k = 0; k < CH; ++k) {
-        const int j = jb + k;
-        n0[k] = (j < m && j0 < m) ? sYY[j0 * P + j] : 0.0f;
-        n1[k] = (j < m && j1 < m) ? sYY[j1 * P + j] : 0.0f;
+        const int j = min(jb + k, m - 1);
+        n0[k] = sYY[r0 + j];
+        n1[k] = sYY[r1 + j];
       }
     };
-    fetch(0);
-    for (int jb = 0; jb < m; jb += CH) {
+    fetch(jfrom);
+    for (int jb = jfrom; jb < jto; jb += CH) {
       float c0[CH], c1[CH];
 #pragma unroll
       for (int k = 0; k < CH; ++k) { c0[k] = n0[k]; c1[k] = n1[k]; }
-      if (jb + CH < m) fetch(jb + CH);
+      if (jb + CH < jto) fetch(jb + CH);
 #pragma unroll
       for (int k = 0; k < CH; ++k) {
         const int j = jb + k;
-        if (j >= m) break;
-        const double cyj = bcast(j >= 64 ? cy1 : cy0, j & 63);
+        if (j >= jto) break;
+        const double cyj = bcast(hi ? cy1 : cy0, hi ? j - 64 : j);
         b0 += cyj * (double)c0[k];
         b1 += cyj * (double)c1[k];
       }
     }
-  }
-  {
+  };
+  walk2(lo_t{}, 0, m < 64 ? m : 64);
+  walk2(hi_t{}, 64, m);
+  SOLVE_STAMP(5);
+  // walk 3, i = 0 .. m-1:  cs_i = al_i - ro_i * b_i,  b_own += cs_i * SY[i][own]  (own newer than i)
+  auto walk3 = [&](auto HI, int ifrom, int ito) {       // i = ifrom .. ito-1
+    constexpr bool hi = decltype(HI)::value;
+    if (ifrom >= ito) return;
     float n0[CH], n1[CH];
-    auto fetch = [&](int ib) {                 // row entries SY[ib + k][own] = (y_own . s_i)
+    auto fetch = [&](int ib) {                 // row entries SY[ib + k][own] (zero unless own > i)
 #pragma unroll
       for (int k = 0; k < CH; ++k) {
-        const int i = ib + k;
-        n0[k] = (i < m && j0 > i && j0 < m) ? sSY[i * P + j0] : 0.0f;
-        n1[k] = (i < m && j1 > i && j1 < m) ? sSY[i * P + j1] : 0.0f;
+        const int i = min(ib + k, m - 1);
+        if (!hi) n0[k] = sSY[i * P + q0];      // from 64 on no slot-0 index is newer than i
+        n1[k] = sSY[i * P + q1];
       }
     };
-    fetch(0);
-    for (int ib = 0; ib < m; ib += CH) {
+    fetch(ifrom);
+    for (int ib = ifrom; ib < ito; ib += CH) {
       float c0[CH], c1[CH];
 #pragma unroll
-      for (int k = 0; k < CH; ++k) { c0[k] = n0[k]; c1[k] = n1[k]; }
-      if (ib + CH < m) fetch(ib + CH);
+      for (int k = 0; k < CH; ++k) { c0[k] = hi ? 0.0f : n0[k]; c1[k] = n1[k]; }
+      if (ib + CH < ito) fetch(ib + CH);
 #pragma unroll
       for (int k = 0; k < CH; ++k) {
         const int i = ib + k;
-        if (i >= m) break;
-        const bool hi = i >= 64;
-        const double be = (double)(float)((float)(hi ? b1 : b0) * (float)(hi ? ro1 : ro0));
+        if (i >= ito) break;
+        const int src = hi ? i - 64 : i;
+        const double be = (double)(float)((float)(hi ? b1 : b0) * (hi ? ro1f : ro0f));
         const double cand = (double)(float)((float)(hi ? al1 : al0) - (float)be);
-        const double csi = bcast(cand, i & 63);
-        if (i == j0) cs0 = csi;
-        if (i == j1) cs1 = csi;
-        b0 += csi * (double)c0[k];
+        const double csi = bcast(cand, src);
+        if (lane == src) {
+          if (hi) cs1 = csi; else cs0 = csi;
+        }
+        if (!hi) b0 += csi * (double)c0[k];
         b1 += csi * (double)c1[k];
       }
     }
-  }
+  };
+  walk3(lo_t{}, 0, m < 64 ? m : 64);
+  walk3(hi_t{}, 64, m);
+  SOLVE_STAMP(6);
   double gtd = 0.0;
   if (j0 < m) gtd += cy0 * sh_gy[j0] + cs0 * sh_gs[j0];
   if (j1 < m) gtd += cy1 * sh_gy[j1] + cs1 * sh_gs[j1];
@@ -419,6 +485,7 @@ __global__ __launch_bounds__(256) void solve_kernel(CState* st, CWs w, int hist,
     st->gtd = (float)gtd;
     st->no_update = ((float)gtd > -tol_change) ? 1 : 0;
   }
+  SOLVE_STAMP(7);
 }
 
 // ---- pass B: form the direction, move x, remember g ------------------------------------------------
@@ -525,3 +592,9 @@ extern "C" int stv_lbfgsc_step(float* x, const float* grad, void* state, void* w
   STV_CHECK_LAUNCH();
   return STV_OK;
 }
+
+#ifdef STV_SOLVE_STAMPS
+extern "C" int stv_debug_solve_stamps(unsigned long long* out8) {
+  return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_solve_stamps), sizeof(g_solve_stamps)) == hipSuccess ? 0 : 1;
+}
+#endif

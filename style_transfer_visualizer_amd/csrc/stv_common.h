@@ -116,6 +116,22 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// Same total on the DPP path: four in-row butterflies (quad swaps, half-row and row mirrors) and
+// the two row broadcasts, no trip through the LDS crossbar (ds_bpermute costs an LDS round trip
+// per step).  The total forms in row 3 and is returned wave-uniform.  Different association than
+// wave_sum, so the last bits differ; both are deterministic.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+#define STV_DPP_ADD(ctrl, rows)                                                                        \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rows, 0xF, false))
+  STV_DPP_ADD(0xB1, 0xF);    // quad_perm [1,0,3,2]
+  STV_DPP_ADD(0x4E, 0xF);    // quad_perm [2,3,0,1]
+  STV_DPP_ADD(0x141, 0xF);   // row_half_mirror
+  STV_DPP_ADD(0x140, 0xF);   // row_mirror: every lane holds its row's sum
+  STV_DPP_ADD(0x142, 0xA);   // row_bcast:15 into rows 1 and 3
+  STV_DPP_ADD(0x143, 0xC);   // row_bcast:31 into rows 2 and 3
+#undef STV_DPP_ADD
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
