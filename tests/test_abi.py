@@ -33,7 +33,7 @@ def test_version_and_sizing_helpers_run_without_gpu():
     assert lib.stv_gram_partials_bytes(4096, 512) == lib.stv_gram_ksplit(4096, 512) * 512 * 512 * 4
     assert lib.stv_lbfgs_workspace_bytes(3 * 64 * 64, 100) > 2 * 101 * 3 * 64 * 64 * 4
     assert lib.stv_lbfgsc_workspace_bytes(3 * 64 * 64, 100) > 2 * 101 * 3 * 64 * 64 * 4
-    assert lib.stv_gram_loss_parts(64) * 32 >= 64 * 64
+    assert lib.stv_gram_loss_parts(64) * 128 >= 64 * 64   # one loss partial per 128 Gram elements
 
 
 def test_op_struct_layout_matches_header():
