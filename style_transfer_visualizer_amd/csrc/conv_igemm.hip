@@ -44,7 +44,7 @@ __device__ unsigned long long g_stv_stamps[8 * 16384];
 #define STV_STAMP(k)                                                                              \
   do {                                                                                            \
     if (threadIdx.x == 0) {                                                                       \
-      unsigned long long* s_ = g_stv_stamps + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8;  \
+      unsigned long long* s_ = g_stv_stamps + (size_t)blockIdx.x * 8;  \
       s_[(k)] = __builtin_amdgcn_s_memtime();                                                     \
       if ((k) == 0) s_[6] = __builtin_amdgcn_s_memrealtime();                                     \
       if ((k) == 4) s_[7] = __builtin_amdgcn_s_memrealtime();                                     \
@@ -352,10 +352,25 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
   const int r = lane & 31, h = lane >> 5;
 
   const int tiles_x = (a.W + C::TW - 1) / C::TW;
-  const int tile_x = blockIdx.x % tiles_x;
-  const int tile_y = blockIdx.x / tiles_x;
+  // Block -> (spatial tile, channel block).  Workgroups are dealt to the 8 XCDs round-robin and each
+  // XCD has its own L2, so the channel blocks of one spatial tile are given ids 8 apart: they run
+  // on the same XCD at about the same time and the second one finds the tile's input in that L2
+  // (with a plain 2-D grid every channel block streamed the whole input from HBM again).
+  const int ntiles = tiles_x * ((a.H + C::TH - 1) / C::TH);
+  const int ny = (a.cout + C::BN - 1) / C::BN;
+  int tile, yb;
+  {
+    const int round = 8 * ny, b = (int)blockIdx.x;
+    const int grp8 = b / round, within = b - grp8 * round;
+    const int left = ntiles - grp8 * 8;                    // tiles in this group of (up to) eight
+    const int span = left < 8 ? left : 8;
+    tile = grp8 * 8 + within % span;
+    yb = within / span;
+  }
+  const int tile_x = tile % tiles_x;
+  const int tile_y = tile / tiles_x;
   const int x0 = tile_x * C::TW, y0 = tile_y * C::TH;
-  const int n0 = blockIdx.y * C::BN;
+  const int n0 = yb * C::BN;
 
   const T* __restrict__ xin = static_cast<const T*>(a.x);
   const T* __restrict__ wgt = static_cast<const T*>(a.w);
@@ -635,7 +650,7 @@ int launch_cfg(const ConvArgs& a, hipStream_t st) {
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
   if (attr_rc != hipSuccess) return STV_ERR_LAUNCH;
   const int tiles = ceil_div(a.W, C::TW) * ceil_div(a.H, C::TH);
-  dim3 grid(tiles, ceil_div(a.cout, C::BN));
+  dim3 grid(tiles * ceil_div(a.cout, C::BN));      // decoded XCD-aware in the kernel
   hipLaunchKernelGGL(conv_igemm_kernel<C>, grid, dim3(C::THREADS), C::LDS_BYTES, st, a);
   STV_CHECK_LAUNCH();
   return STV_OK;
