@@ -236,36 +236,45 @@ class _Engine:
         return ops_
 
     def _forward_with_losses(self, x: torch.Tensor, *, style_coef: float, with_seed: bool) -> list:
-        # Batched loss side (default where the activations of one forward pass still fit the Infinity
-        # Cache, i.e. up to ~768^2): the whole forward pass first, then ONE batched Gram chain for all
-        # style taps (stv_gram_multi) and the content terms.  The chain is five latency-bound
-        # problems; in one grid they cost the slowest, not the sum.  Larger images keep the
-        # interleaved order (each tap right behind its producer, while its activation is cache
-        # resident).
+        # Batched loss side: the Gram chain of a tap is a handful of latency-bound launches (partial
+        # sums, finish), and side by side in one grid (stv_gram_multi) several taps cost the slowest
+        # instead of the sum.  Deferring a tap to the end of the forward pass only pays while its
+        # activation is small enough to still sit in the Infinity Cache by then, so the decision is
+        # per tap: taps up to 48 MiB are batched behind the last conv, larger ones keep their place
+        # right behind their producer.  512^2: all five taps batched; 1024^2: the three deep ones.
+        # Same arithmetic and summation order either way (the batched kernels run the per-tap bodies).
         s = self.sched
-        act_bytes = sum(nd.dst.act.numel() * nd.dst.act.element_size() for nd in s.nodes)
         mode = os.environ.get("STV_LOSS_BATCH", "auto")
-        batched = (mode == "1" or (mode == "auto" and act_bytes <= 160 * 2 ** 20)) and 0 < len(s.style_taps) <= 8 \
-            and x.is_cuda
-        if batched:
+        limit = 48 * 2 ** 20
+
+        def small(tap) -> bool:
+            return tap.buf.act.numel() * tap.buf.act.element_size() <= limit
+        deferred = [tap for tap in s.style_taps if mode == "1" or (mode == "auto" and small(tap))]
+        if len(deferred) < 2 or len(deferred) > 8 or not x.is_cuda:
+            deferred = []
+        tail = []
+        if deferred:
             specs = [dict(tap=tap, target=tap.target, loss_part=self.parts[tap.parts_off:],
-                          sgrad=tap.sgrad if with_seed else None, coef=style_coef) for tap in s.style_taps]
-            tail = [s.gram_multi_op(specs)]
+                          sgrad=tap.sgrad if with_seed else None, coef=style_coef) for tap in deferred]
+            tail.append(s.gram_multi_op(specs))
+        if deferred and len(deferred) == len(s.style_taps):
             for tap in s.content_taps:
                 tail += self._tap_loss_ops(tap, style_coef=style_coef, coef_dev=None, with_seed=with_seed)
             return s.forward_ops(x) + tail
+        held = {id(tap) for tap in deferred}
 
         def after(node):
             out = []
             for tap in node.dst.taps:
-                out += self._tap_loss_ops(tap, style_coef=style_coef, coef_dev=None, with_seed=with_seed)
+                if id(tap) not in held:
+                    out += self._tap_loss_ops(tap, style_coef=style_coef, coef_dev=None, with_seed=with_seed)
             return out
         if os.environ.get("STV_LOSS_INTERLEAVE", "1") == "1":
-            return self.sched.forward_ops(x, after_node=after)
-        tail = []
+            return self.sched.forward_ops(x, after_node=after) + tail
+        inline = []
         for node in self.sched.nodes:
-            tail += after(node)
-        return self.sched.forward_ops(x) + tail
+            inline += after(node)
+        return self.sched.forward_ops(x) + inline + tail
 
     def _combine_op(self, style_w: float, content_w: float):
         op = self.sched._op(op=plan.OP_LOSS_COMBINE, p0=self.parts, p1=self.table, p2=self.scale,

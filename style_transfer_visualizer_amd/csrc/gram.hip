@@ -207,6 +207,16 @@ struct GramBCfg {
   static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
 };
 
+// Diagnostic build (-DSTV_GRAM_STAMPS): wave 0 of block 0 accumulates 100 MHz wall-clock time per
+// loop phase (MFMA phase, wait for the next stage's loads, LDS writes, barrier) and the prologue /
+// epilogue; tools/gram_stamps.py reads them back.
+#ifdef STV_GRAM_STAMPS
+__device__ unsigned long long g_gram_stamps[8];
+#define GRAM_T() wall_clock64()
+#else
+#define GRAM_T() 0ull
+#endif
+
 template <int TS>
 __device__ __forceinline__ void gram_partial_bf16_body(const bf16_t* __restrict__ F, float* __restrict__ partials,
                                                        int N, int C, int ksplit, int chunk, int bx, int by) {
@@ -279,10 +289,14 @@ __device__ __forceinline__ void gram_partial_bf16_body(const bf16_t* __restrict_
   (void)rs;
 
   const int nstages = (p_end > p_begin) ? (p_end - p_begin + PKB - 1) / PKB : 0;
+  unsigned long long tt[6] = {0, 0, 0, 0, 0, 0};
+  const unsigned long long t_begin = GRAM_T();
   stage_load(p_begin, nstages > 0);
   stage_write(smem);
   __syncthreads();
+  const unsigned long long t_loop = GRAM_T();
   for (int s = 0; s < nstages; ++s) {
+    const unsigned long long t0 = GRAM_T();
     char* cur = smem + (s & 1) * G::STAGE_BYTES;
     char* nxt = smem + ((s + 1) & 1) * G::STAGE_BYTES;
     stage_load(p_begin + (s + 1) * PKB, (s + 1) < nstages);
@@ -317,9 +331,22 @@ __device__ __forceinline__ void gram_partial_bf16_body(const bf16_t* __restrict_
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
+#ifdef STV_GRAM_STAMPS
+    const unsigned long long t1 = GRAM_T();
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the next stage's loads have landed
+    const unsigned long long t2 = GRAM_T();
+    stage_write(nxt);
+    __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0)
+    const unsigned long long t3 = GRAM_T();
+    __syncthreads();
+    const unsigned long long t4 = GRAM_T();
+    tt[0] += t1 - t0; tt[1] += t2 - t1; tt[2] += t3 - t2; tt[3] += t4 - t3;
+#else
     stage_write(nxt);
     __syncthreads();
+#endif
   }
+  const unsigned long long t_end = GRAM_T();
 
   const int r = lane & 31, h = lane >> 5;
   float* out = partials + (size_t)ks * C * C;
@@ -333,6 +360,12 @@ __device__ __forceinline__ void gram_partial_bf16_body(const bf16_t* __restrict_
         const int col = j0 + wj * (G::AT * 32) + b * 32 + r;
         if (row < C && col < C) out[(size_t)row * C + col] = acc[a][b][i];
       }
+#ifdef STV_GRAM_STAMPS
+  if (bx == 0 && by == 0 && tid == 0) {
+    g_gram_stamps[0] = tt[0]; g_gram_stamps[1] = tt[1]; g_gram_stamps[2] = tt[2]; g_gram_stamps[3] = tt[3];
+    g_gram_stamps[4] = t_loop - t_begin; g_gram_stamps[5] = GRAM_T() - t_end; g_gram_stamps[6] = nstages;
+  }
+#endif
 }
 
 template <int TS>
@@ -672,3 +705,9 @@ extern "C" int stv_gram_multi(const stv_gram_tap_t* taps, int n_taps, int dtype,
   }
   return STV_OK;
 }
+
+#ifdef STV_GRAM_STAMPS
+extern "C" int stv_debug_gram_stamps(unsigned long long* out8) {
+  return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_gram_stamps), sizeof(g_gram_stamps)) == hipSuccess ? 0 : 1;
+}
+#endif
