@@ -659,9 +659,10 @@ int launch_cfg(const ConvArgs& a, hipStream_t st) {
 // ---- tile choice --------------------------------------------------------------------------------
 // Configurations: 0 = 8x128, 1 = 8x64, 2 = 4x128, 3 = 4x64 (TH x BN), 4 = 4x64 with K split over two
 // wave groups, 5 = 8x64 and 6 = 4x64 on a two-deep LDS ring (two / three workgroups per CU),
-// 7 = 2x64 with the K split (the 32x32-pixel layers: four times the workgroups of 4x64 x 2).  -1 = the shape is outside the matrix-core tiling (direct fallback).
-constexpr int kNumCfg = 8;
-const int kCfgTH[kNumCfg] = {8, 8, 4, 4, 4, 8, 4, 2}, kCfgBN[kNumCfg] = {128, 64, 128, 64, 64, 64, 64, 64};
+// 7 = 2x64 with the K split (the 32x32-pixel layers: four times the workgroups of 4x64 x 2),
+// 8 = 1x64 with the K split in four-wave workgroups (a 32x32-pixel layer then covers all 256 CUs).  -1 = the shape is outside the matrix-core tiling (direct fallback).
+constexpr int kNumCfg = 9;
+const int kCfgTH[kNumCfg] = {8, 8, 4, 4, 4, 8, 4, 2, 1}, kCfgBN[kNumCfg] = {128, 64, 128, 64, 64, 64, 64, 64, 64};
 
 bool cfg_valid(int cfg, int cout) { return cfg >= 0 && cfg < kNumCfg && !(cout <= 64 && kCfgBN[cfg] == 128); }
 
@@ -718,6 +719,7 @@ int launch_mfma(const ConvArgs& a, int cfg, hipStream_t st) {
     case 5: return launch_cfg<Cfg<T, 8, 64, 4, 2, TAPS, 1, 2>>(a, st);
     case 6: return launch_cfg<Cfg<T, 4, 64, 2, 2, TAPS, 1, 2>>(a, st);
     case 7: return launch_cfg<Cfg<T, 2, 64, 2, 2, TAPS, 2>>(a, st);
+    case 8: return launch_cfg<Cfg<T, 1, 64, 1, 2, TAPS, 2>>(a, st);
     default: return launch_cfg<Cfg<T, 4, 64, 2, 2, TAPS>>(a, st);
   }
 }
@@ -725,7 +727,7 @@ int launch_mfma(const ConvArgs& a, int cfg, hipStream_t st) {
 template <typename T, int TAPS>
 int launch_typed(const ConvArgs& a, hipStream_t st) {
   int cfg = choose_cfg(a.H, a.W, a.cin, a.cout, (int)sizeof(T), TAPS);
-  if (cfg == 7 && a.pool != nullptr) cfg = 4;      // a 2-row tile holds one row per wave: no pooling window
+  if ((cfg == 7 || cfg == 8) && a.pool != nullptr) cfg = 4;      // a 2-row tile holds one row per wave: no pooling window
   if (cfg < 0) {
     const size_t total = (size_t)a.H * a.W * a.cout;
     hipLaunchKernelGGL((conv_direct_kernel<T, TAPS>), dim3((unsigned)((total + 255) / 256)),

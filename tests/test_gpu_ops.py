@@ -185,7 +185,7 @@ def test_conv_igemm_with_fused_maxpool(dtype, cfg, case, monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("case", [(128, 128, 21, 70), (64, 64, 9, 33), (48, 136, 12, 40), (512, 128, 8, 8)])
 def test_conv_igemm_every_tile_config(dtype, cfg, case, monkeypatch):
     """Each tile shape / wave layout / K split (forced with STV_CONV_CFG) on full, ragged and odd-K shapes."""

@@ -17,7 +17,7 @@ for (H, W, cin, cout) in shapes:
     b = torch.zeros(cout, device=dev)
     y = torch.empty(H, W, cout, device=dev, dtype=dtype)
     row = []
-    for cfg in range(8):
+    for cfg in range(9):
         os.environ["STV_CONV_CFG"] = str(cfg)
         if cout <= 64 and cfg in (0, 2):
             row.append("   -  ")
