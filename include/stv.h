@@ -46,7 +46,8 @@ enum {
   STV_RELU_OUT = 2,  /* apply max(0,.) before storing (conv+ReLU fusion) */
   STV_MASK = 4,      /* multiply result by (ref > 0): ReLU backward */
   STV_ACCUM = 8,     /* out += result instead of out = result */
-  STV_W_BLOCKED = 16 /* conv weights are K-blocked: [taps][cin/CK][cout][CK], CK = 32 bytes of `dtype` */
+  STV_W_BLOCKED = 16, /* conv weights are K-blocked: [taps][cin/CK][cout][CK], CK = 32 bytes of `dtype` */
+  STV_POOL_IDX = 32   /* stv_maxpool_bwd: `x` is the arg-max byte map of stv_conv_igemm_pool, not the activation */
 };
 
 int stv_version(void);
@@ -109,9 +110,14 @@ int stv_conv_igemm(const void* x, const void* w, const float* bias, const void* 
  * NHWC [H/2][W/2][cout]) from the same epilogue: replaces the conv2d + relu +
  * max_pool2d run of `x = block(x)` (core_model.py:316) where a pool follows the
  * conv.  Matrix-core shapes only (stv_conv_config >= 0), else STV_ERR_ARG and the
- * caller pools with stv_maxpool_fwd.  flags: RELU_IN, RELU_OUT, W_BLOCKED. */
+ * caller pools with stv_maxpool_fwd.  flags: RELU_IN, RELU_OUT, W_BLOCKED.
+ * `pool_idx` (optional, [H/2][W/2][cout] bytes) receives what max_pool2d's backward needs
+ * instead of the full-resolution activation: bits 0-1 = window position (2*dy + dx) of the
+ * first maximum in scan order, bit 2 = that maximum is > 0 (the ReLU mask of the winner);
+ * decided on the values as stored in `y`.  stv_maxpool_bwd takes it with STV_POOL_IDX. */
 int stv_conv_igemm_pool(const void* x, const void* w, const float* bias, void* y, void* y_pool,
-                        int H, int W, int cin, int cout, int flags, int dtype, void* stream);
+                        void* pool_idx, int H, int W, int cin, int cout, int flags, int dtype,
+                        void* stream);
 
 /* Two-term gradient in one launch:
  *   y = [accumulate onto y +] mask(ref > 0) * conv3x3(x, w)  +  x2 . w2^T
@@ -133,7 +139,9 @@ int stv_conv_igemm_dual(const void* x, const void* w, const void* x2, const void
 int stv_conv_config(int H, int W, int cin, int cout, int taps, int dtype);
 
 /* MaxPool2d(2,2) forward / backward (first-max-wins like torch); backward
- * optionally applies the ReLU mask of the stored pre-pool activation. */
+ * optionally applies the ReLU mask of the stored pre-pool activation (STV_MASK) and
+ * accumulates (STV_ACCUM).  With STV_POOL_IDX `x` is the [H/2][W/2][C] byte map written by
+ * stv_conv_igemm_pool: the pass then reads 1 byte instead of 4 activations per window. */
 int stv_maxpool_fwd(const void* x, void* y, int H, int W, int C, int dtype, void* stream);
 int stv_maxpool_bwd(const void* x, const void* dy, void* dx, int H, int W, int C,
                     int flags, int dtype, void* stream);
@@ -238,7 +246,7 @@ enum {
 enum { STV_LANE_SIDE = 1 << 29, STV_LANE_JOIN = 1 << 30 };
 /* Operands follow the direct entry points' argument order (inputs p0.., outputs q0..).
  * CONV_FIRST_FWD takes the optional stv_conv_first_pack buffer in p3, CONV_FIRST_DGRAD in p2;
- * CONV with q1 set runs stv_conv_igemm_pool (q1 = pooled output); CONV with q2/q3 set runs
+ * CONV with q1 set runs stv_conv_igemm_pool (q1 = pooled output, q2 = optional arg-max map); CONV with q2 AND q3 set runs
  * stv_conv_igemm_dual (q2 = x2, q3 = w2, n = cin2: inputs, despite the slot names).
  * GRAM_MULTI: p0 = HOST pointer to an array of stv_gram_tap_t, n = its length; the array is
  * copied into the program when it is created. */

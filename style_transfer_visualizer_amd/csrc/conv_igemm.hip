@@ -117,6 +117,7 @@ struct ConvArgs {
   void* y;
   int H, W, cin, cout, flags;
   void* pool;   // optional second output: MaxPool2d(2,2) of y, [H/2][W/2][cout]
+  void* pool_idx;  // optional third output with it: one byte per pooled element (stv.h: stv_conv_igemm_pool)
   // optional fused 1x1 term: y = epilogue(mask(ref) * conv3x3(x, w) + x2 . w2^T), x2 [H][W][cin2],
   // w2 [cout][cin2] plain rows (the Gram backward product riding in the dgrad that shares its output)
   const void* x2;
@@ -601,6 +602,51 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
         return ((r & 1) == 0 && gyp < Hp && gxp < Wp) ? (uint32_t)(((gyp * Wp + gxp) * a.cout) * (int)sizeof(T)) : kOob;
       };
       emit([&](int mp, int nt, int i) { return pm[mp < C::MT / 2 ? mp : 0][nt][i]; }, pool_off, rs_p, C::MT / 2, false, false);
+
+      // Arg-max map for the pooling backward (stv_maxpool_bwd with STV_POOL_IDX): per pooled element
+      // one byte, bits 0-1 = window position of the FIRST maximum in scan order (row-major, torch),
+      // bit 2 = that maximum is positive.  Decided on the values as stored (bias, ReLU, storage
+      // rounding applied), so it is the decision a pooling pass over y would take.
+      if (a.pool_idx != nullptr) {
+        const __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc(a.pool_idx, 0, Hp * Wp * a.cout, 0x00020000);
+        auto stored = [&](float v) -> float {
+          if (relu_out) v = fmaxf(v, 0.0f);
+          if constexpr (sizeof(T) == 2) v = bf16_to_f32(f32_to_bf16(v));
+          return v;
+        };
+        auto right = [](float v) -> float {       // the neighbouring lane's value (quad_perm [1,0,3,2])
+          return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+        };
+#pragma unroll
+        for (int mp = 0; mp < C::MT / 2; ++mp) {
+          const int gyp = ((y0 + wm * C::MT) >> 1) + mp, gxp = (x0 + r) >> 1;
+          const bool pix_ok = (r & 1) == 0 && gyp < Hp && gxp < Wp;
+#pragma unroll
+          for (int nt = 0; nt < C::NT; ++nt) {
+            const int nb = n0 + wn * (C::NT * 32) + nt * 32;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              uint32_t word = 0;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float tl = stored(acc[2 * mp][nt][4 * j + e] + bias_v[nt][j][e]);
+                const float bl = stored(acc[2 * mp + 1][nt][4 * j + e] + bias_v[nt][j][e]);
+                const float tr = right(tl), br = right(bl);
+                float best = tl;
+                uint32_t code = 0;
+                if (tr > best) { best = tr; code = 1; }
+                if (bl > best) { best = bl; code = 2; }
+                if (br > best) { best = br; code = 3; }
+                if (best > 0.0f) code |= 4;
+                word |= code << (8 * e);
+              }
+              const int nn = nb + 8 * j + 4 * h;
+              const uint32_t off = (pix_ok && nn < a.cout) ? (uint32_t)((gyp * Wp + gxp) * a.cout + nn) : kOob;
+              __builtin_amdgcn_raw_buffer_store_b32(word, rs_i, off, 0, 0);
+            }
+          }
+        }
+      }
     }
   }
   STV_STAMP(4);
@@ -759,7 +805,7 @@ int tune_typed(int H, int W, int cin, int cout, int taps, hipStream_t st) {
   const size_t words = (bx + bw) / 4;
   hipLaunchKernelGGL(tune_fill_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st,
                      reinterpret_cast<uint32_t*>(buf), words, 0x9E3779B9u);
-  ConvArgs a{buf, buf + bx, nullptr, nullptr, buf + bx + bw, H, W, cin, cout, STV_W_BLOCKED, nullptr, nullptr, nullptr, 0};
+  ConvArgs a{buf, buf + bx, nullptr, nullptr, buf + bx + bw, H, W, cin, cout, STV_W_BLOCKED, nullptr, nullptr, nullptr, nullptr, 0};
   if (taps == 1) a.flags = 0;
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
@@ -830,7 +876,7 @@ extern "C" int stv_conv_igemm(const void* x, const void* w, const float* bias, c
   // the direct fallback (shapes the matrix-core tiling does not cover) reads plain weights only
   if ((flags & STV_W_BLOCKED) && choose_cfg(H, W, cin, cout, dtype == STV_F32 ? 4 : 2, taps) < 0) return STV_ERR_ARG;
   if ((size_t)H * W * (size_t)(cin > cout ? cin : cout) >= (size_t)1 << 31) return STV_ERR_ARG;
-  ConvArgs a{x, w, bias, ref, y, H, W, cin, cout, flags, nullptr, nullptr, nullptr, 0};
+  ConvArgs a{x, w, bias, ref, y, H, W, cin, cout, flags, nullptr, nullptr, nullptr, nullptr, 0};
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dtype == STV_F32)
     return taps == 9 ? launch_typed<float, 9>(a, st) : launch_typed<float, 1>(a, st);
@@ -840,14 +886,15 @@ extern "C" int stv_conv_igemm(const void* x, const void* w, const float* bias, c
 }
 
 extern "C" int stv_conv_igemm_pool(const void* x, const void* w, const float* bias, void* y, void* y_pool,
-                                   int H, int W, int cin, int cout, int flags, int dtype, void* stream) {
+                                   void* pool_idx, int H, int W, int cin, int cout, int flags, int dtype,
+                                   void* stream) {
   if (!x || !w || !y || !y_pool || H <= 1 || W <= 1 || cin <= 0 || cout <= 0) return STV_ERR_ARG;
   if (flags & (STV_MASK | STV_ACCUM)) return STV_ERR_ARG;                     // forward convolutions only
   if ((size_t)H * W * (size_t)(cin > cout ? cin : cout) >= (size_t)1 << 31) return STV_ERR_ARG;
   if (dtype != STV_F32 && dtype != STV_BF16) return STV_ERR_ARG;
   // the fused pool lives in the matrix-core kernel's epilogue: other shapes pool separately
   if (choose_cfg(H, W, cin, cout, dtype == STV_F32 ? 4 : 2, 9) < 0) return STV_ERR_ARG;
-  ConvArgs a{x, w, bias, nullptr, y, H, W, cin, cout, flags, y_pool, nullptr, nullptr, 0};
+  ConvArgs a{x, w, bias, nullptr, y, H, W, cin, cout, flags, y_pool, pool_idx, nullptr, nullptr, 0};
   hipStream_t st = static_cast<hipStream_t>(stream);
   return dtype == STV_F32 ? launch_typed<float, 9>(a, st) : launch_typed<bf16_t, 9>(a, st);
 }
@@ -864,7 +911,7 @@ extern "C" int stv_conv_igemm_dual(const void* x, const void* w, const void* x2,
   const int es = dtype == STV_F32 ? 4 : 2;
   // both terms run in the matrix-core kernel: its channel granularity applies to both K extents
   if (choose_cfg(H, W, cin, cout, es, 9) < 0 || cin2 % (32 / es)) return STV_ERR_ARG;
-  ConvArgs a{x, w, nullptr, ref, y, H, W, cin, cout, flags, nullptr, x2, w2, cin2};
+  ConvArgs a{x, w, nullptr, ref, y, H, W, cin, cout, flags, nullptr, nullptr, x2, w2, cin2};
   hipStream_t st = static_cast<hipStream_t>(stream);
   return dtype == STV_F32 ? launch_typed<float, 9>(a, st) : launch_typed<bf16_t, 9>(a, st);
 }

@@ -104,6 +104,65 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
   }
 }
 
+// Same routing from the arg-max byte map of the fused conv+pool epilogue (one byte per pooled
+// element: bits 0-1 = window position of the first maximum, bit 2 = maximum > 0): the pass reads
+// dy and kVec bytes per window instead of four activation vectors.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_idx_kernel(const unsigned char* __restrict__ idx,
+                                                              const T* __restrict__ dy, T* __restrict__ dx,
+                                                              int H, int W, int C, int flags) {
+  constexpr int kVec = elem_traits<T>::kVec;
+  const int Ho = H / 2, Wo = W / 2, CV = C / kVec;
+  const int Hc = (H + 1) / 2, Wc = (W + 1) / 2;  // cover odd tails
+  const bool mask = (flags & STV_MASK) != 0;
+  const bool accum = (flags & STV_ACCUM) != 0;
+  const size_t total = (size_t)Hc * Wc * CV;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int cv = (int)(i % CV);
+    const size_t p = i / CV;
+    const int ox = (int)(p % Wc), oy = (int)(p / Wc);
+    const int iy = 2 * oy, ix = 2 * ox;
+    const bool inside = oy < Ho && ox < Wo;
+    float g[kVec], out[4][kVec];
+    unsigned char code[kVec];
+#pragma unroll
+    for (int e = 0; e < kVec; ++e) { g[e] = 0.0f; code[e] = 0; }
+    if (inside) {
+      const size_t o = ((size_t)oy * Wo + ox) * C + cv * kVec;
+      unpack16<T>(*reinterpret_cast<const u32x4*>(dy + o), g);
+      if constexpr (kVec == 8) {
+        const unsigned long long w = *reinterpret_cast<const unsigned long long*>(idx + o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) code[e] = (unsigned char)(w >> (8 * e));
+      } else {
+        const unsigned int w = *reinterpret_cast<const unsigned int*>(idx + o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) code[e] = (unsigned char)(w >> (8 * e));
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < kVec; ++e) {
+      const bool live = inside && (!mask || (code[e] & 4));
+#pragma unroll
+      for (int q = 0; q < 4; ++q) out[q][e] = (live && (code[e] & 3) == q) ? g[e] : 0.0f;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int yy = iy + (q >> 1), xx = ix + (q & 1);
+      if (yy < H && xx < W) {
+        T* o = dx + ((size_t)yy * W + xx) * C + cv * kVec;
+        if (accum) {
+          float old[kVec];
+          unpack16<T>(*reinterpret_cast<const u32x4*>(o), old);
+#pragma unroll
+          for (int e = 0; e < kVec; ++e) out[q][e] += old[e];
+        }
+        *reinterpret_cast<u32x4*>(o) = pack16<T>(out[q]);
+      }
+    }
+  }
+}
+
 // scalar variants for channel counts that are not a multiple of the vector width
 template <typename T>
 __global__ void maxpool_fwd_scalar(const T* __restrict__ x, T* __restrict__ y, int H, int W, int C) {
@@ -306,6 +365,15 @@ int pool_fwd_typed(const void* x, void* y, int H, int W, int C, hipStream_t st) 
 }
 template <typename T>
 int pool_bwd_typed(const void* x, const void* dy, void* dx, int H, int W, int C, int flags, hipStream_t st) {
+  if (flags & STV_POOL_IDX) {
+    if (C % elem_traits<T>::kVec) return STV_ERR_ARG;      // the byte map only exists for matrix-core shapes
+    const size_t items = (size_t)((H + 1) / 2) * ((W + 1) / 2) * (C / elem_traits<T>::kVec);
+    hipLaunchKernelGGL(maxpool_bwd_idx_kernel<T>, dim3(grid_for(items)), dim3(256), 0, st,
+                       static_cast<const unsigned char*>(x), static_cast<const T*>(dy), static_cast<T*>(dx), H, W, C,
+                       flags);
+    STV_CHECK_LAUNCH();
+    return STV_OK;
+  }
   if (C % elem_traits<T>::kVec == 0) {
     const size_t items = (size_t)((H + 1) / 2) * ((W + 1) / 2) * (C / elem_traits<T>::kVec);
     hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(grid_for(items)), dim3(256), 0, st,

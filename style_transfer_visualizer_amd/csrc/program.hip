@@ -42,8 +42,8 @@ int run_op(const stv_op_t& op, void* st) {
         return stv_conv_igemm_dual(o.p0, o.p1, o.q2, o.q3, o.p3, o.q0, o.H, o.W, o.cin, (int)o.n, o.cout,
                                    o.flags, o.dtype, st);
       if (o.q1)    // forward conv with the following MaxPool2d(2,2) fused into its epilogue
-        return stv_conv_igemm_pool(o.p0, o.p1, static_cast<const float*>(o.p2), o.q0, o.q1, o.H, o.W, o.cin,
-                                   o.cout, o.flags, o.dtype, st);
+        return stv_conv_igemm_pool(o.p0, o.p1, static_cast<const float*>(o.p2), o.q0, o.q1, o.q2, o.H, o.W, o.cin,
+                                   o.cout, o.flags, o.dtype, st);    // q2 (optional, q3 unset): arg-max byte map
       return stv_conv_igemm(o.p0, o.p1, static_cast<const float*>(o.p2), o.p3, o.q0, o.H, o.W, o.cin,
                             o.cout, o.taps, o.flags, o.dtype, st);
     case STV_OP_POOL_FWD:

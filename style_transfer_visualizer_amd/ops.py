@@ -165,8 +165,9 @@ def conv_igemm(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = Non
 
 def conv_igemm_pool(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None, flags: int = 0,
                     out: torch.Tensor | None = None, pool_out: torch.Tensor | None = None,
-                    ) -> tuple[torch.Tensor, torch.Tensor]:
-    """3x3 conv (+bias, +ReLU by flag) and MaxPool2d(2,2) of its output in one launch (stv_conv_igemm_pool)."""
+                    pool_idx: torch.Tensor | None = None) -> tuple[torch.Tensor, torch.Tensor]:
+    """3x3 conv (+bias, +ReLU by flag) and MaxPool2d(2,2) of its output in one launch (stv_conv_igemm_pool).
+    ``pool_idx`` (uint8 [H/2][W/2][cout], optional) receives the arg-max map ``maxpool_bwd_idx`` consumes."""
     H, W, cin = x.shape
     if w.dim() == 4:
         taps, nck, cout, ck = w.shape
@@ -181,8 +182,8 @@ def conv_igemm_pool(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None,
     if pool_out is None:
         pool_out = torch.empty(H // 2, W // 2, cout, device=x.device, dtype=x.dtype)
     lib = _lib.load()
-    _lib.check(lib.stv_conv_igemm_pool(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), _ptr(pool_out), H, W, cin, cout,
-                                       flags, dtype_code(x.dtype), _stream()), "stv_conv_igemm_pool")
+    _lib.check(lib.stv_conv_igemm_pool(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), _ptr(pool_out), _ptr(pool_idx), H, W,
+                                       cin, cout, flags, dtype_code(x.dtype), _stream()), "stv_conv_igemm_pool")
     return out, pool_out
 
 
@@ -242,6 +243,18 @@ def maxpool_fwd(x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tenso
     lib = _lib.load()
     _lib.check(lib.stv_maxpool_fwd(_ptr(x), _ptr(out), H, W, C, dtype_code(x.dtype), _stream()),
                "stv_maxpool_fwd")
+    return out
+
+
+def maxpool_bwd_idx(idx: torch.Tensor, dy: torch.Tensor, H: int, W: int, out: torch.Tensor | None = None,
+                    flags: int = 0) -> torch.Tensor:
+    """Pooling backward from the arg-max byte map of ``conv_igemm_pool`` (H, W: the un-pooled size)."""
+    C = dy.shape[-1]
+    if out is None:
+        out = torch.empty(H, W, C, device=dy.device, dtype=dy.dtype)
+    lib = _lib.load()
+    _lib.check(lib.stv_maxpool_bwd(_ptr(idx), _ptr(dy), _ptr(out), H, W, C, flags | _lib.POOL_IDX,
+                                   dtype_code(dy.dtype), _stream()), "stv_maxpool_bwd")
     return out
 
 

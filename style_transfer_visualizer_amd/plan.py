@@ -27,7 +27,7 @@ import torch
 from torch import nn
 
 from . import _lib, ops
-from ._lib import (ACCUM, MASK, W_BLOCKED, OP_GRAM_MULTI, OP_CONTENT_GRAD, OP_CONTENT_LOSS, OP_CONV, OP_CONV_FIRST_DGRAD,
+from ._lib import (ACCUM, MASK, POOL_IDX, W_BLOCKED, OP_GRAM_MULTI, OP_CONTENT_GRAD, OP_CONTENT_LOSS, OP_CONV, OP_CONV_FIRST_DGRAD,
                    OP_CONV_FIRST_FWD, OP_GRAM_FINISH, OP_GRAM_PARTIAL, OP_LOSS_COMBINE, OP_POOL_BWD,
                    OP_POOL_FWD, OP_RELU_BWD, OP_RELU_FWD, RELU_IN, RELU_OUT, StvOp)
 
@@ -58,6 +58,7 @@ class Node:
     wb: torch.Tensor | None = None
     bias: torch.Tensor | None = None
     cin: int = 0
+    idx: torch.Tensor | None = None     # pool nodes fused into a conv: arg-max byte map for the backward
 
 
 @dataclass
@@ -225,6 +226,10 @@ class Schedule:
                     and d.relu_fused and nd.wf.dim() == 4 and d.act.is_cuda):
                 pool_dst = nxt.dst.act
                 fused.add(id(nxt))
+                # the fused epilogue also leaves the arg-max map the pooling backward needs: one byte
+                # per pooled element instead of re-reading the full-resolution activation
+                if self.with_grad and nxt.idx is None and os.environ.get("STV_POOL_IDX", "1") != "0":
+                    nxt.idx = torch.empty(nxt.dst.H, nxt.dst.W, nxt.dst.C, device=self.device, dtype=torch.uint8)
             if id(nd) in fused:
                 if after_node is not None:
                     out += after_node(nd)
@@ -235,7 +240,8 @@ class Schedule:
             elif nd.kind == "conv":
                 flags = ((RELU_IN if nd.relu_in else 0) | (RELU_OUT if d.relu_fused else 0)
                          | (W_BLOCKED if nd.wf.dim() == 4 else 0))
-                out.append(self._op(op=OP_CONV, p0=nd.src.act, p1=nd.wf, p2=nd.bias, q0=d.act, q1=pool_dst, H=d.H,
+                out.append(self._op(op=OP_CONV, p0=nd.src.act, p1=nd.wf, p2=nd.bias, q0=d.act, q1=pool_dst,
+                                    q2=nxt.idx if pool_dst is not None else None, H=d.H,
                                     W=d.W, cin=nd.cin, cout=d.C, taps=9, flags=flags))
             elif nd.kind == "pool":
                 out.append(self._op(op=OP_POOL_FWD, p0=nd.src.act, q0=d.act, H=nd.src.H, W=nd.src.W, cin=d.C))
@@ -348,8 +354,12 @@ class Schedule:
                                         H=s.H, W=s.W, cin=d.C, cout=s.C, taps=9, flags=flags))
             elif nd.kind == "pool":
                 flags = (MASK if (s.relu_fused and not s.taps) else 0) | acc_flag(s)
-                out.append(self._op(op=OP_POOL_BWD, p0=s.act, p1=d.grad, q0=s.grad, H=s.H, W=s.W, cin=s.C,
-                                    flags=flags))
+                if nd.idx is not None:      # written by the forward conv that carried this pool
+                    out.append(self._op(op=OP_POOL_BWD, p0=nd.idx, p1=d.grad, q0=s.grad, H=s.H, W=s.W, cin=s.C,
+                                        flags=flags | POOL_IDX))
+                else:
+                    out.append(self._op(op=OP_POOL_BWD, p0=s.act, p1=d.grad, q0=s.grad, H=s.H, W=s.W, cin=s.C,
+                                        flags=flags))
             else:  # materialised relu
                 out.append(self._op(op=OP_RELU_BWD, p0=s.act, p1=d.grad, q0=s.grad, n=s.act.numel(),
                                     flags=acc_flag(s)))

@@ -162,7 +162,7 @@ def test_conv_igemm_dual_dgrad_plus_gram_term(dtype, cfg, flags, case, monkeypat
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [None, 0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("cfg", [None, 0, 1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("case", [(64, 64, 33, 70), (128, 128, 16, 40), (64, 128, 9, 33), (256, 256, 8, 8)])
 def test_conv_igemm_with_fused_maxpool(dtype, cfg, case, monkeypatch):
     """One launch writes relu(conv) and MaxPool2d(2,2) of it (odd sizes drop the last row / column like torch)."""
@@ -176,12 +176,24 @@ def test_conv_igemm_with_fused_maxpool(dtype, cfg, case, monkeypatch):
     b = rnd((cout,), 53, -0.2, 0.2)
     ref = F.relu(F.conv2d(q(x, dtype), q(w, dtype), b, padding=1))
     wp = ops.block_weights(ops.pack_weights_fwd(w).to(dtype).to(DEV))
-    y, yp = ops.conv_igemm_pool(ops.to_nhwc(x, dtype).to(DEV), wp, b.to(DEV), flags=ops.RELU_OUT)
+    idx = torch.full((H // 2, W // 2, cout), 255, device=DEV, dtype=torch.uint8)
+    y, yp = ops.conv_igemm_pool(ops.to_nhwc(x, dtype).to(DEV), wp, b.to(DEV), flags=ops.RELU_OUT, pool_idx=idx)
     assert_close(ops.from_nhwc(y), ref, dtype, 9 * cin, f"conv {case}")
     assert yp.shape == (H // 2, W // 2, cout)
     # the pooled map is exactly the pool of the stored map (same rounding, max commutes with it)
     want = F.max_pool2d(ops.from_nhwc(y).cpu(), 2, 2)
     assert torch.equal(ops.from_nhwc(yp).cpu(), want)
+    # the arg-max map is the decision a pooling pass over the stored map takes (first maximum in scan
+    # order, winner > 0): routing the gradient through it equals the activation-based backward, bit
+    # for bit, with and without the ReLU mask / accumulate
+    assert int(idx.max()) <= 7
+    dy = ops.to_nhwc(rnd((1, cout, H // 2, W // 2), 54), dtype).to(DEV)
+    for flags in (0, ops.MASK, ops.MASK | ops.ACCUM):
+        seed = ops.to_nhwc(rnd((1, cout, H, W), 55), dtype).to(DEV)
+        a, b2 = seed.clone(), seed.clone()
+        ops.maxpool_bwd(y, dy, out=a, flags=flags)
+        ops.maxpool_bwd_idx(idx, dy, H, W, out=b2, flags=flags)
+        assert torch.equal(a, b2), f"idx backward differs, flags={flags}"
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
