@@ -135,7 +135,7 @@ int stv_conv_igemm_dual(const void* x, const void* w, const void* x2, const void
 /* Which tile the dispatcher picks for a shape: -1 = scalar fallback (channel counts not a
  * multiple of the MFMA K-slice), else 0..3 = {8x128, 8x64, 4x128, 4x64} (rows x couts) and
  * 4 = 4x64 with K split over two wave groups, 5 = 8x64 and 6 = 4x64 with a two-deep LDS ring,
- * 7 = 2x64 with the K split. */
+ * 7 = 2x64 and 8 = 1x64 (four waves) with the K split. */
 int stv_conv_config(int H, int W, int cin, int cout, int taps, int dtype);
 
 /* MaxPool2d(2,2) forward / backward (first-max-wins like torch); backward
