@@ -574,7 +574,7 @@ int fwd_typed(const float* x, const float* wf, const float* packed, const float*
               int cin, int cout, hipStream_t st) {
   if (cin == 3 && cout == 64 && packed && std::is_same<T, bf16_t>::value && !getenv("STV_FIRST_VALU")) {
     const int tiles = ceil_div(W, MF_TW) * ceil_div(H, MF_TH);
-    static const int wg_per_cu = getenv("STV_FIRST_WGS") ? atoi(getenv("STV_FIRST_WGS")) : 4;
+    static const int wg_per_cu = getenv("STV_FIRST_WGS") ? atoi(getenv("STV_FIRST_WGS")) : 2;   // swept 2..8: 2 is fastest at 512^2 and 1024^2
     const int grid = tiles < wg_per_cu * 256 ? tiles : wg_per_cu * 256;   // resident workgroups walk the tiles
     hipLaunchKernelGGL(conv_first_fwd_mfma, dim3(grid), dim3(256), 0, st, x,
                        reinterpret_cast<const uint32_t*>(packed + 2 * 1728), bias, static_cast<bf16_t*>(y), H, W);
