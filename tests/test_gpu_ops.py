@@ -131,9 +131,10 @@ def test_conv_igemm_forward(dtype, case, flags, blocked):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [None, 0, 1, 3, 4, 5, 7])
+@pytest.mark.parametrize("cfg", [None, 0, 1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("flags", [0, ops.MASK, ops.ACCUM, ops.MASK | ops.ACCUM])
-@pytest.mark.parametrize("case", [(128, 64, 33, 70), (256, 128, 16, 40), (64, 64, 9, 33), (512, 256, 8, 8)])
+@pytest.mark.parametrize("case", [(128, 64, 33, 70), (256, 128, 16, 40), (64, 64, 9, 33), (512, 256, 8, 8),
+                                  (96, 48, 20, 36)])   # 48 channels: not whole multi-slice stages -> general 1x1 loop
 def test_conv_igemm_dual_dgrad_plus_gram_term(dtype, cfg, flags, case, monkeypatch):
     """out = [prev +] mask(z>0) * dgrad(dy, w) + F . S^T in one launch: the mask touches the first term only."""
     cd, cs, H, W = case            # channels of the layer above (dy) and of this layer (output, F, S)
