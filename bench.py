@@ -297,7 +297,7 @@ def cpu_baseline(size: int, threads: int) -> dict:
     def closure():
         _s, _c, t, g = ocm.loss_and_grad(model, x, 1e5, 1.0)
         return t, g
-    warm, timed = 2, (6 if size <= 512 else 2)
+    warm, timed = 2, (24 if size <= 512 else 6)     # ~10-15 s of CPU work at 512^2 on 16 cores
     for _ in range(warm):
         opt.step(closure)
     t0 = time.perf_counter()
