@@ -212,6 +212,7 @@ __global__ __launch_bounds__(256) void solve_kernel(CState* st, CWs w, int hist,
   __shared__ int sh_skip, sh_pushed, sh_m, sh_head, sh_cslot, sh_mold;
   __shared__ float sh_newro, sh_H;
   __shared__ double sh_gs[MAX_S], sh_gy[MAX_S], sh_ro[MAX_S];
+  __shared__ double sh_bp[4][128];       // per-wave partial sums of the second walk
   const int tid = threadIdx.x;
   const double* D = w.dots;
   const double* SC = w.dots + 5 * MAX_HIST;
@@ -338,14 +339,16 @@ __global__ __launch_bounds__(256) void solve_kernel(CState* st, CWs w, int hist,
   }
   __syncthreads();
   SOLVE_STAMP(3);
-  if (tid >= 64) return;
 
-  // ---- one wave: torch's two-loop on coefficients; lane owns logical indices lane, lane+64 ----
+  // ---- torch's two-loop on coefficients; a lane owns logical indices lane, lane+64 ----
+  // All four waves run the first (serial) walk redundantly - each on its own SIMD, same registers,
+  // same result - so that the second walk, a plain matrix-vector product, can be split over them
+  // without a hand-over of state; the third walk and the tail are wave 0's alone.
   // Written as broadcast + rank-1 updates: when alpha_i (beta_i) becomes known its owner lane
   // broadcasts it with v_readlane and every other lane folds it into the running sum of the
   // indices it owns, so the serial chain per iteration is one FMA + one readlane instead of a
   // 6-step cross-lane reduction.
-  const int lane = tid;
+  const int lane = tid & 63, wave4 = tid >> 6;
   const int j0 = lane, j1 = lane + 64;
   auto bcast = [](double v, int src) -> double {          // src is wave-uniform
     const long long bits = __double_as_longlong(v);
@@ -441,8 +444,20 @@ __global__ __launch_bounds__(256) void solve_kernel(CState* st, CWs w, int hist,
       }
     }
   };
-  walk2(lo_t{}, 0, m < 64 ? m : 64);
-  walk2(hi_t{}, 64, m);
+  {
+    // wave w takes j in [32w, 32w + 32): slot 0 owners for w < 2, slot 1 owners above
+    const double init0 = b0, init1 = b1;
+    b0 = 0.0; b1 = 0.0;
+    const int jb = wave4 * 32, je = m < jb + 32 ? m : jb + 32;
+    if (wave4 < 2) walk2(lo_t{}, jb, je);
+    else walk2(hi_t{}, jb, je);
+    sh_bp[wave4][lane] = b0;
+    sh_bp[wave4][64 + lane] = b1;
+    __syncthreads();
+    if (tid >= 64) return;
+    b0 = init0 + ((sh_bp[0][lane] + sh_bp[1][lane]) + (sh_bp[2][lane] + sh_bp[3][lane]));
+    b1 = init1 + ((sh_bp[0][64 + lane] + sh_bp[1][64 + lane]) + (sh_bp[2][64 + lane] + sh_bp[3][64 + lane]));
+  }
   SOLVE_STAMP(5);
   // walk 3, i = 0 .. m-1:  cs_i = al_i - ro_i * b_i,  b_own += cs_i * SY[i][own]  (own newer than i)
   auto walk3 = [&](auto HI, int ifrom, int ito) {       // i = ifrom .. ito-1
