@@ -195,6 +195,16 @@ int stv_content_loss(const void* F, const void* target, float* loss_part, size_t
 int stv_content_grad(const void* F, const void* target, void* dF, size_t n, float coef,
                      const float* coef_dev, int flags, int dtype, void* stream);
 
+/* ---- Frame / PNG export: prepare_image_for_output (image_io.py:129-152: denormalise,
+ *      nan_to_num(nan=0, posinf=1, neginf=0), clamp 0..1) fused with the uint8 conversion, on the
+ *      device, so only H*W*3 bytes cross to the host.  x NCHW fp32 [3][H][W] -> out HWC uint8.
+ *      mean3/std3: HOST arrays of 3 floats (ImageNet statistics, constants.py:11-12) or both NULL
+ *      for an un-normalised image.  round = 0: (uint8)(v*255), the truncating frame conversion of
+ *      optimization.py:445-451; round = 1: (uint8)clamp(v*255 + 0.5, 0, 255), what
+ *      torchvision.utils.save_image does for the final PNG (runtime/output.py:101). */
+int stv_image_to_u8(const float* x_nchw, uint8_t* out_hwc, int H, int W, const float* mean3,
+                    const float* std3, int round, void* stream);
+
 /* ---- Score combine: torch.stack(losses).sum() and
  *      loss = style_w*style + content_w*content (optimization.py:298-312).
  *  table: int32 [n_terms][3] = {offset into parts, count, kind(0 style,1 content)}

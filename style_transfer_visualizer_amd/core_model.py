@@ -36,35 +36,48 @@ def resolve_precision(precision: str | None = None) -> torch.dtype:
 
 # --------------------------------------------------------------------------- gram
 class _GramFn(torch.autograd.Function):
-    """clamp(F F^T, max)/(b*c*h*w) for an NCHW tensor, via the split-K MFMA Gram kernels."""
+    """clamp(F F^T, max)/(b*c*h*w) for an NCHW tensor, via the split-K MFMA Gram kernels.
+
+    Any ``b*c`` is accepted, like the reference: the channel axis is zero-padded to the kernels'
+    granularity (8) - padded channels only add zero rows/columns, which are sliced away again.
+    """
+
+    _PAD = 8
 
     @staticmethod
     def forward(ctx, tensor: torch.Tensor, clamp_max: float) -> torch.Tensor:
+        if tensor.dim() != 4:
+            msg = f"gram_matrix expects a [batch, channels, h, w] tensor, got shape {tuple(tensor.shape)}"
+            raise ValueError(msg)
         b, c, h, w = tensor.shape
         C, n = b * c, h * w
-        if C % 4:
-            msg = f"gram_matrix kernel needs b*c to be a multiple of 4, got {C}"
-            raise RuntimeError(msg)
-        feat = tensor.detach().reshape(C, n).t().contiguous().float()     # [N, C] (NHWC view)
+        Cp = -(-C // _GramFn._PAD) * _GramFn._PAD
+        feat = tensor.detach().reshape(C, n).t().float()                 # [N, C] (NHWC view)
+        if Cp != C:
+            feat = torch.nn.functional.pad(feat, (0, Cp - C))
+        feat = feat.contiguous()
+        norm = float(C * n)
         partials = ops.gram_partial(feat)
-        gram = torch.empty(C, C, device=tensor.device, dtype=torch.float32)
-        raw = torch.empty(C, C, device=tensor.device, dtype=torch.float32)
-        ops.gram_finish(partials, n, C, gram_out=gram, clamp_max=clamp_max)
-        ops.gram_finish(partials, n, C, gram_out=raw, clamp_max=float("inf"))
+        gram = torch.empty(Cp, Cp, device=tensor.device, dtype=torch.float32)
+        raw = torch.empty(Cp, Cp, device=tensor.device, dtype=torch.float32)
+        ops.gram_finish(partials, n, Cp, gram_out=gram, clamp_max=clamp_max, norm=norm)
+        ops.gram_finish(partials, n, Cp, gram_out=raw, clamp_max=float("inf"), norm=1.0)    # R itself
         ctx.save_for_backward(feat, raw)
         ctx.meta = (b, c, h, w, clamp_max)
-        return gram.to(tensor.dtype)
+        return gram[:C, :C].to(tensor.dtype)
 
     @staticmethod
     def backward(ctx, gout: torch.Tensor):
         feat, raw = ctx.saved_tensors
         b, c, h, w, clamp_max = ctx.meta
         C, n = b * c, h * w
-        norm = float(C * n)
-        seed = gout.float() * (raw * norm <= clamp_max).float() / norm
+        Cp = raw.shape[0]
+        g = torch.zeros(Cp, Cp, device=raw.device, dtype=torch.float32)
+        g[:C, :C] = gout.float()
+        seed = g * (raw <= clamp_max).float() / float(C * n)           # clamp passes gradient where R <= max
         seed = (seed + seed.t()).contiguous()                           # dF^T = F^T (dR + dR^T)
-        d_feat = ops.conv_igemm(feat.reshape(1, n, C), seed.reshape(1, C, C))
-        return d_feat.reshape(n, C).t().reshape(b, c, h, w).to(gout.dtype), None
+        d_feat = ops.conv_igemm(feat.reshape(1, n, Cp), seed.reshape(1, Cp, Cp))
+        return d_feat.reshape(n, Cp)[:, :C].t().reshape(b, c, h, w).to(gout.dtype), None
 
 
 def gram_matrix(tensor: torch.Tensor, clamp_max: float = GRAM_MATRIX_CLAMP_MAX) -> torch.Tensor:
@@ -212,6 +225,10 @@ class _Engine:
         self.coef_buf = torch.ones(max(n_terms, 1), device=device, dtype=torch.float32)
         self._programs: dict = {}
         self.use_graph = os.environ.get("STV_HIP_GRAPH", "1") != "0"
+        # Every evaluation overwrites the shared activation buffers; an autograd backward is only
+        # valid against the forward that filled them last.  `generation` counts evaluations.
+        self.generation = 0
+        self._stage: torch.Tensor | None = None      # fp32 contiguous copy of a non-conforming input
 
     # -- op list pieces -------------------------------------------------------
     def _tap_loss_ops(self, tap, *, style_coef: float, coef_dev: torch.Tensor | None, with_seed: bool) -> list:
@@ -286,12 +303,27 @@ class _Engine:
     def _program(self, key: tuple, builder) -> plan.Program:
         prog = self._programs.get(key)
         if prog is None:
+            if len(self._programs) >= 16:     # programs are keyed by buffer addresses: bound the cache (oldest out)
+                self._programs.pop(next(iter(self._programs)))
             prog = plan.Program(builder(), self.sched._keep)
             self._programs[key] = prog
         return prog
 
     # -- targets ---------------------------------------------------------------
+    def stage_input(self, x: torch.Tensor) -> torch.Tensor:
+        """A contiguous fp32 view of ``x``: ``x`` itself when it already is one, else a copy into one
+        persistent staging buffer (a fresh temporary per call would key a new program + hipGraph by
+        its address every time)."""
+        xd = x.detach()
+        if xd.is_contiguous() and xd.dtype == torch.float32:
+            return xd
+        if self._stage is None or self._stage.shape != xd.shape:
+            self._stage = torch.empty(xd.shape, device=self.device, dtype=torch.float32)
+        self._stage.copy_(xd)
+        return self._stage
+
     def capture_content(self, content_img: torch.Tensor) -> list[torch.Tensor]:
+        self.generation += 1
         x = content_img.detach().contiguous().float()
         plan.Program(self.sched.forward_ops(x), self.sched._keep + [x]).run()
         targets = [tap.buf.act.clone() for tap in self.sched.content_taps]
@@ -300,6 +332,7 @@ class _Engine:
         return targets
 
     def capture_style(self, style_img: torch.Tensor) -> list[torch.Tensor]:
+        self.generation += 1
         x = style_img.detach().contiguous().float()
         Hs, Ws = x.shape[-2:]
         sched = (self.sched if (Hs, Ws) == (self.H, self.W) else
@@ -328,13 +361,33 @@ class _Engine:
             changed |= tap.target is None or tap.target.data_ptr() != t.data_ptr()
             tap.target = t
         for tap, t in zip(self.sched.content_taps, content_targets, strict=True):
-            if t.dim() == 4:    # NCHW as the reference stores it -> NHWC storage
-                t = ops.to_nhwc(t, self.dtype)
+            if t.dim() == 4:    # [1,C,H,W] as the reference stores it -> NHWC storage
+                t = self._nhwc_of(t)
             t = self._as_target(t, tuple(tap.buf.act.shape), self.dtype)
             changed |= tap.target is None or tap.target.data_ptr() != t.data_ptr()
             tap.target = t
         if changed:
             self._programs.clear()
+
+    def _nhwc_of(self, t: torch.Tensor) -> torch.Tensor:
+        """NHWC ``[H,W,C]`` storage of a ``[1,C,H,W]`` target.  The views ``set_targets`` publishes
+        are recognised (channels-last strides, storage dtype): no copy.  Anything else is converted
+        once and cached per (tensor, version) - this runs on every evaluation."""
+        if t.shape[0] != 1:
+            msg = f"content target must have batch size 1, got shape {tuple(t.shape)}"
+            raise RuntimeError(msg)
+        v = t[0].permute(1, 2, 0)
+        if v.is_contiguous() and v.dtype == self.dtype and v.device == self.device:
+            return v
+        cache = self.__dict__.setdefault("_target_cache", {})
+        key = (t.data_ptr(), t._version, tuple(t.shape), t.dtype)
+        hit = cache.get(key)
+        if hit is None:
+            if len(cache) > 8:
+                cache.clear()
+            hit = v.to(self.device, self.dtype).contiguous()
+            cache[key] = hit
+        return hit
 
     def _as_target(self, t: torch.Tensor, shape: tuple, dtype: torch.dtype) -> torch.Tensor:
         if tuple(t.shape) != shape:
@@ -346,6 +399,7 @@ class _Engine:
 
     # -- execution -------------------------------------------------------------
     def loss_and_grad(self, x: torch.Tensor, grad: torch.Tensor, style_w: float, content_w: float) -> None:
+        self.generation += 1
         key = ("fused", x.data_ptr(), grad.data_ptr(), style_w, content_w)
 
         def build():
@@ -356,6 +410,7 @@ class _Engine:
         self._program(key, build).run(self.use_graph)
 
     def forward_losses(self, x: torch.Tensor) -> None:
+        self.generation += 1
         key = ("fwd", x.data_ptr())
 
         def build():
@@ -382,17 +437,21 @@ class _LossesFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x: torch.Tensor, engine: _Engine) -> torch.Tensor:
-        xc = x.detach()
-        if not xc.is_contiguous() or xc.dtype != torch.float32:
-            xc = xc.contiguous().float()
-        engine.forward_losses(xc)
+        engine.forward_losses(engine.stage_input(x))
         ctx.engine = engine
+        ctx.generation = engine.generation
         ctx.x_meta = (x.shape, x.dtype)
         return engine.losses.clone()
 
     @staticmethod
     def backward(ctx, gout: torch.Tensor):
         engine: _Engine = ctx.engine
+        if engine.generation != ctx.generation:
+            # the engine keeps ONE set of activations per image size: a later model(x'),
+            # loss_and_grad or set_targets has overwritten what this backward would differentiate
+            msg = ("StyleContentModel: backward() of a forward pass whose activations were overwritten by a later "
+                   "evaluation of the same model (call backward() before evaluating the model again).")
+            raise RuntimeError(msg)
         shape, dtype = ctx.x_meta
         grad = torch.empty(shape, device=engine.device, dtype=torch.float32)
         engine.backward_from(gout.contiguous().float(), grad)
@@ -426,6 +485,18 @@ class StyleContentModel(nn.Module):
     def _layers(self) -> list[nn.Module]:
         return [layer for block in self.vgg_blocks for layer in block]
 
+    def _check_image(self, x: torch.Tensor) -> None:
+        if not isinstance(x, torch.Tensor) or not x.is_cuda or x.dim() != 4 or x.shape[0] != 1:
+            msg = f"expected a GPU image of shape [1, C, H, W], got {tuple(x.shape) if isinstance(x, torch.Tensor) else type(x)}"
+            raise RuntimeError(msg)
+        # the condition torch's conv2d rejects in the reference; here the first-layer kernel takes
+        # cin from the weights and would otherwise read out of bounds
+        first = next((layer for layer in self._layers() if isinstance(layer, nn.Conv2d)), None)
+        if first is not None and int(x.shape[1]) != first.in_channels:
+            msg = (f"expected input with {first.in_channels} channels (the first convolution's in_channels), "
+                   f"got {int(x.shape[1])} channels in shape {tuple(x.shape)}")
+            raise RuntimeError(msg)
+
     def _engine_for(self, x: torch.Tensor) -> _Engine:
         if not isinstance(x, torch.Tensor) or not x.is_cuda:
             msg = ("StyleContentModel runs on the MI355X HIP kernels only: the image must be a GPU tensor "
@@ -437,6 +508,7 @@ class StyleContentModel(nn.Module):
         if not self._style_at and not self._content_at:
             msg = "no style or content layers configured"
             raise RuntimeError(msg)
+        self._check_image(x)
         H, W = int(x.shape[-2]), int(x.shape[-1])
         key = (H, W, x.device.index)
         eng = self._engines.get(key)
@@ -451,8 +523,11 @@ class StyleContentModel(nn.Module):
         if not style_img.is_cuda:
             msg = "style image must be a GPU tensor (no CPU fallback on this path)"
             raise RuntimeError(msg)
+        self._check_image(style_img)
         self.style_targets = eng.capture_style(style_img)
-        self.content_targets = eng.capture_content(content_img)
+        # public form as in the reference (core_model.py:230-232): [1, C, H, W].  They are zero-copy
+        # NCHW views of the engine's NHWC buffers (channels-last strides, storage dtype).
+        self.content_targets = [t.permute(2, 0, 1).unsqueeze(0) for t in eng.capture_content(content_img)]
 
     def _require_targets(self) -> None:
         # same order and texts as reference core_model.py:255-258, 287-290

@@ -631,13 +631,7 @@ int dgrad_typed(const void* dy, const float* wf, const float* packed, float* dx,
     }
     const int tiles = ceil_div(W, FT) * ceil_div(H, FT);
     const size_t lds = (size_t)FH * FH * (64 * sizeof(T) + 16);
-    static bool attr = false;
-    if (!attr) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_first_dgrad_c64<T>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return STV_ERR_LAUNCH;
-      attr = true;
-    }
+    if (stv_set_max_lds(reinterpret_cast<const void*>(&conv_first_dgrad_c64<T>), (int)lds) != STV_OK) return STV_ERR_LAUNCH;
     hipLaunchKernelGGL(conv_first_dgrad_c64<T>, dim3(tiles), dim3(256), lds, st, static_cast<const T*>(dy), wd, dx,
                        H, W);
     STV_CHECK_LAUNCH();

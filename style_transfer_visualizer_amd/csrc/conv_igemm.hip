@@ -691,10 +691,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs a) {
 
 template <typename C>
 int launch_cfg(const ConvArgs& a, hipStream_t st) {
-  // once per instantiation and process (thread-safe: callers may drive several streams)
-  static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<C>),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-  if (attr_rc != hipSuccess) return STV_ERR_LAUNCH;
+  if (stv_set_max_lds(reinterpret_cast<const void*>(&conv_igemm_kernel<C>), C::LDS_BYTES) != STV_OK) return STV_ERR_LAUNCH;
   const int tiles = ceil_div(a.W, C::TW) * ceil_div(a.H, C::TH);
   dim3 grid(tiles * ceil_div(a.cout, C::BN));      // decoded XCD-aware in the kernel
   hipLaunchKernelGGL(conv_igemm_kernel<C>, grid, dim3(C::THREADS), C::LDS_BYTES, st, a);

@@ -501,13 +501,8 @@ template <int TS>
 int launch_bf16(const bf16_t* F, float* partials, int N, int C, int pairs, int ksplit, hipStream_t st) {
   int chunk = ceil_div(N, ksplit);
   chunk = ceil_div(chunk, PKB) * PKB;
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_partial_bf16_kernel<TS>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, GramBCfg<TS>::LDS_BYTES) != hipSuccess)
-      return STV_ERR_LAUNCH;
-    attr = true;
-  }
+  if (stv_set_max_lds(reinterpret_cast<const void*>(&gram_partial_bf16_kernel<TS>), GramBCfg<TS>::LDS_BYTES) != STV_OK)
+    return STV_ERR_LAUNCH;
   hipLaunchKernelGGL((gram_partial_bf16_kernel<TS>), dim3(pairs * ksplit), dim3(256), GramBCfg<TS>::LDS_BYTES, st,
                      F, partials, N, C, ksplit, chunk, pairs);
   STV_CHECK_LAUNCH();
@@ -532,14 +527,8 @@ int partial_typed(const void* F, float* partials, int N, int C, hipStream_t st) 
     hipLaunchKernelGGL((gram_partial_kernel<T, 64>), grid, dim3(256), GramCfg<64>::LDS_BYTES, st,
                        static_cast<const T*>(F), partials, N, C, ksplit, chunk, pairs);
   } else {
-    static bool attr = false;
-    if (!attr) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_partial_kernel<T, 128>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                              GramCfg<128>::LDS_BYTES) != hipSuccess)
-        return STV_ERR_LAUNCH;
-      attr = true;
-    }
+    if (stv_set_max_lds(reinterpret_cast<const void*>(&gram_partial_kernel<T, 128>), GramCfg<128>::LDS_BYTES) != STV_OK)
+      return STV_ERR_LAUNCH;
     hipLaunchKernelGGL((gram_partial_kernel<T, 128>), grid, dim3(256), GramCfg<128>::LDS_BYTES, st,
                        static_cast<const T*>(F), partials, N, C, ksplit, chunk, pairs);
   }
@@ -648,13 +637,7 @@ extern "C" int stv_gram_multi(const stv_gram_tap_t* taps, int n_taps, int dtype,
     const dim3 grid(m.block0[m.n]);
 #define STV_SET_LDS(kern, bytes)                                                                             \
   do {                                                                                                       \
-    static bool done = false;                                                                                \
-    if (!done) {                                                                                             \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                              bytes) != hipSuccess)                                                          \
-        return STV_ERR_LAUNCH;                                                                               \
-      done = true;                                                                                           \
-    }                                                                                                        \
+    if (stv_set_max_lds(reinterpret_cast<const void*>(&kern), bytes) != STV_OK) return STV_ERR_LAUNCH;      \
   } while (0)
     if (dtype == STV_BF16) {
       if (TS == 64) {

@@ -590,14 +590,8 @@ extern "C" int stv_lbfgsc_step(float* x, const float* grad, void* state, void* w
   const int nparts = ntiles * 4;
   const CWs w = carve(workspace, n, history, nparts);
   const size_t lds = 2 * (size_t)history * (size_t)(history | 1) * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize,
-                            2 * MAX_HIST * (MAX_HIST | 1) * (int)sizeof(float)) != hipSuccess)
-      return STV_ERR_LAUNCH;
-    attr = true;
-  }
+  if (stv_set_max_lds(reinterpret_cast<const void*>(&solve_kernel), 2 * MAX_HIST * (MAX_HIST | 1) * (int)sizeof(float)) != STV_OK)
+    return STV_ERR_LAUNCH;
   if (tile == 4096)
     hipLaunchKernelGGL(pass_a_kernel<4>, dim3(ntiles), dim3(256), 0, st, grad, s, w, n, nn, history, nparts);
   else if (tile == 2048)

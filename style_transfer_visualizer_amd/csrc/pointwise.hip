@@ -386,6 +386,52 @@ int pool_bwd_typed(const void* x, const void* dy, void* dx, int H, int W, int C,
   return STV_OK;
 }
 
+
+// ------------------------------------------------------------- frame export
+// prepare_image_for_output + the uint8 conversion of the frame / PNG path (reference
+// image_io.py:118-152, optimization.py:445-451, torchvision save_image at runtime/output.py:101):
+//   v = x*std + mean (two roundings, as torch evaluates it) when `normalize`;
+//   nan -> 0, +inf -> 1, -inf -> 0; clamp to [0,1];
+//   round == 0: (uint8)(v*255)            (frames: numpy astype truncation)
+//   round == 1: (uint8)clamp(v*255+0.5)   (save_image)
+// x: NCHW fp32 [3][H][W] -> out: HWC uint8 [H][W][3].  One thread converts four pixels.
+struct FrameStats { float mean[3], std[3]; };
+
+__device__ __forceinline__ uint32_t frame_u8(float v, float mean, float stdv, int normalize, int round) {
+  if (normalize) v = __fadd_rn(__fmul_rn(v, stdv), mean);      // no fma: torch does mul then add
+  if (v != v) v = 0.0f;
+  v = fminf(fmaxf(v, 0.0f), 1.0f);                               // +-inf land on 1 / 0 like nan_to_num + clamp
+  float s = __fmul_rn(v, 255.0f);
+  if (round) s = fminf(fmaxf(__fadd_rn(s, 0.5f), 0.0f), 255.0f);
+  return (uint32_t)s;
+}
+
+__global__ __launch_bounds__(256) void frame_u8_kernel(const float* __restrict__ x, uint8_t* __restrict__ out,
+                                                       size_t npix, FrameStats st, int normalize, int round) {
+  const size_t quads = (npix + 3) / 4;
+  const bool vec_ok = (npix % 4) == 0;
+  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < quads; q += (size_t)gridDim.x * 256) {
+    const size_t p0 = q * 4;
+    uint32_t b[12];
+    if (vec_ok) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)c * npix + p0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) b[3 * k + c] = frame_u8(v[k], st.mean[c], st.std[c], normalize, round);
+      }
+      uint32_t w[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) w[j] = b[4 * j] | (b[4 * j + 1] << 8) | (b[4 * j + 2] << 16) | (b[4 * j + 3] << 24);
+      uint32_t* o = reinterpret_cast<uint32_t*>(out + p0 * 3);
+      o[0] = w[0]; o[1] = w[1]; o[2] = w[2];
+    } else {
+      for (int k = 0; k < 4 && p0 + k < npix; ++k)
+        for (int c = 0; c < 3; ++c)
+          out[(p0 + k) * 3 + c] = (uint8_t)frame_u8(x[(size_t)c * npix + p0 + k], st.mean[c], st.std[c], normalize, round);
+    }
+  }
+}
 }  // namespace
 
 extern "C" int stv_maxpool_fwd(const void* x, void* y, int H, int W, int C, int dtype, void* stream) {
@@ -475,6 +521,20 @@ extern "C" int stv_loss_combine(const float* parts, const int32_t* table, const 
   if (n_terms > 64) return STV_ERR_ARG;
   hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), parts,
                      table, scale, n_terms, style_w, content_w, losses, scores);
+  STV_CHECK_LAUNCH();
+  return STV_OK;
+}
+
+extern "C" int stv_image_to_u8(const float* x_nchw, uint8_t* out_hwc, int H, int W, const float* mean3,
+                               const float* std3, int round, void* stream) {
+  if (!x_nchw || !out_hwc || H <= 0 || W <= 0 || (round != 0 && round != 1)) return STV_ERR_ARG;
+  if ((mean3 == nullptr) != (std3 == nullptr)) return STV_ERR_ARG;
+  FrameStats st{};
+  const int normalize = mean3 != nullptr;
+  for (int c = 0; c < 3 && normalize; ++c) { st.mean[c] = mean3[c]; st.std[c] = std3[c]; }   // HOST arrays
+  const size_t npix = (size_t)H * W;
+  hipLaunchKernelGGL(frame_u8_kernel, dim3(grid_for((npix + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     x_nchw, out_hwc, npix, st, normalize, round);
   STV_CHECK_LAUNCH();
   return STV_OK;
 }

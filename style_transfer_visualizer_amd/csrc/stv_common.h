@@ -4,6 +4,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+#include <utility>
+#include <vector>
+
 #include "../../include/stv.h"
 
 typedef uint16_t bf16_t;  // raw bf16 storage
@@ -162,3 +166,19 @@ __device__ __forceinline__ float block_max_256(float v, float* smem4) {
 }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device).  Function attributes
+// are per device and callers may launch from several threads / onto several devices, so a plain
+// `static bool` guard is neither thread-safe nor sufficient for a second device.
+inline int stv_set_max_lds(const void* fn, int bytes) {
+  static std::mutex mu;
+  static std::vector<std::pair<const void*, int>> done;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return STV_ERR_LAUNCH;
+  std::lock_guard<std::mutex> lk(mu);
+  for (const auto& e : done)
+    if (e.first == fn && e.second == dev) return STV_OK;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return STV_ERR_LAUNCH;
+  done.emplace_back(fn, dev);
+  return STV_OK;
+}

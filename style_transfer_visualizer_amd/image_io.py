@@ -72,9 +72,44 @@ def prepare_image_for_output(tensor: torch.Tensor, *, normalize: bool) -> torch.
     return img.clamp(0, 1)
 
 
-def save_image(tensor: torch.Tensor, path: str | Path) -> None:
-    """``torchvision.utils.save_image`` for one image: ``mul(255).add(0.5).clamp(0,255)`` -> uint8 PNG."""
+def _on_gpu_path(tensor: torch.Tensor) -> bool:
+    t = tensor
+    return (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32
+            and t.dim() in (3, 4) and t.shape[-3] == 3 and (t.dim() == 3 or t.shape[0] == 1))
+
+
+def frame_uint8(tensor: torch.Tensor, *, normalize: bool) -> np.ndarray | None:
+    """``[H,W,3]`` uint8 frame of the image being optimised (reference optimization.py:438-452):
+    ``prepare_image_for_output`` then the TRUNCATING ``(x * 255).astype("uint8")``.
+
+    A GPU image is converted on the device by ``stv_image_to_u8`` (one kernel, H*W*3 bytes to the
+    host); a host tensor - the runner also drives CPU stand-in models in tests - takes the torch ops
+    the reference uses."""
+    if _on_gpu_path(tensor):
+        from . import ops  # noqa: PLC0415
+        u8 = ops.image_to_u8(tensor, mean=IMAGENET_MEAN if normalize else None,
+                             std=IMAGENET_STD if normalize else None, rounding=False)
+        return u8.cpu().numpy()
+    image = prepare_image_for_output(tensor, normalize=normalize)
+    if image is None:
+        return None
+    return (image.squeeze(0).permute(1, 2, 0).cpu().numpy() * 255).astype("uint8")
+
+
+def save_image(tensor: torch.Tensor, path: str | Path, *, normalize: bool | None = None) -> None:
+    """``torchvision.utils.save_image`` for one image: ``mul(255).add(0.5).clamp(0,255)`` -> uint8 PNG.
+
+    ``normalize`` given: ``tensor`` is the raw optimised image and ``prepare_image_for_output`` is
+    applied first (reference runtime/output.py:92-101) - on the device for a GPU tensor."""
+    if normalize is not None and _on_gpu_path(tensor):
+        from . import ops  # noqa: PLC0415
+        arr = ops.image_to_u8(tensor, mean=IMAGENET_MEAN if normalize else None,
+                              std=IMAGENET_STD if normalize else None, rounding=True).cpu().numpy()
+        Image.fromarray(arr).save(str(path))
+        return
     img = tensor.detach()
+    if normalize is not None:
+        img = prepare_image_for_output(img, normalize=normalize)
     if img.dim() == 4:
         img = img[0]
     arr = img.mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to("cpu", torch.uint8).numpy()

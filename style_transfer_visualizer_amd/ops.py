@@ -311,10 +311,14 @@ def gram_partial(F: torch.Tensor, partials: torch.Tensor | None = None) -> torch
 def gram_finish(partials: torch.Tensor, n_pixels: int, C: int, *, target: torch.Tensor | None = None,
                 gram_out: torch.Tensor | None = None, loss_part: torch.Tensor | None = None,
                 sgrad: torch.Tensor | None = None, clamp_max: float = 5e5, coef: float = 1.0,
-                coef_dev: torch.Tensor | None = None, dtype: torch.dtype = torch.float32) -> None:
+                coef_dev: torch.Tensor | None = None, dtype: torch.dtype = torch.float32,
+                norm: float | None = None) -> None:
+    """``norm`` defaults to ``C * n_pixels`` (the reference's ``b*c*h*w``); callers that padded the
+    channel axis pass the un-padded product."""
     lib = _lib.load()
     _lib.check(lib.stv_gram_finish(_ptr(partials), _ptr(target), _ptr(gram_out), _ptr(loss_part), _ptr(sgrad),
-                                   n_pixels, C, clamp_max, float(C * n_pixels), coef, _ptr(coef_dev),
+                                   n_pixels, C, clamp_max, float(C * n_pixels) if norm is None else float(norm),
+                                   coef, _ptr(coef_dev),
                                    dtype_code(dtype), _stream()), "stv_gram_finish")
 
 
@@ -336,6 +340,35 @@ def loss_combine(parts: torch.Tensor, table: torch.Tensor, scale: torch.Tensor, 
     lib = _lib.load()
     _lib.check(lib.stv_loss_combine(_ptr(parts), _ptr(table), _ptr(scale), table.shape[0], style_w, content_w,
                                     _ptr(losses), _ptr(scores), _stream()), "stv_loss_combine")
+
+
+# ---- frame / PNG export ---------------------------------------------------------
+
+def image_to_u8(x: torch.Tensor, *, mean: tuple | list | None, std: tuple | list | None, rounding: bool,
+                out: torch.Tensor | None = None) -> torch.Tensor:
+    """[1,3,H,W] (or [3,H,W]) fp32 GPU image -> [H,W,3] uint8 GPU tensor (stv_image_to_u8).
+
+    ``mean``/``std`` given: the image is ImageNet-normalised and is denormalised first; ``rounding``
+    False = truncating ``*255`` (frames), True = ``+0.5`` rounding (final PNG)."""
+    img = x.detach()
+    if img.dim() == 4:
+        if img.shape[0] != 1:
+            msg = f"expected one image, got a batch of {img.shape[0]}"
+            raise RuntimeError(msg)
+        img = img[0]
+    if img.dim() != 3 or img.shape[0] != 3 or img.dtype != torch.float32:
+        msg = f"expected a float32 [3,H,W] image, got {tuple(img.shape)} {img.dtype}"
+        raise RuntimeError(msg)
+    img = img.contiguous()
+    _, H, W = img.shape
+    if out is None:
+        out = torch.empty(H, W, 3, device=img.device, dtype=torch.uint8)
+    m3 = (ctypes.c_float * 3)(*mean) if mean is not None else None
+    s3 = (ctypes.c_float * 3)(*std) if std is not None else None
+    lib = _lib.load()
+    _lib.check(lib.stv_image_to_u8(_ptr(img), _ptr(out), H, W, m3, s3, 1 if rounding else 0, _stream()),
+               "stv_image_to_u8")
+    return out
 
 
 # ---- optimizers ---------------------------------------------------------------

@@ -356,11 +356,9 @@ class OptimizationRunner:
                 or (self.video_writer is None and self.gif_collector is None)):
             return
         with torch.no_grad():
-            image = image_io.prepare_image_for_output(self.input_img, normalize=self.config.optimization.normalize)
-            if image is None:
+            frame = image_io.frame_uint8(self.input_img, normalize=self.config.optimization.normalize)
+            if frame is None:
                 return
-            # truncating conversion, like reference optimization.py:445-451
-            frame = (image.squeeze(0).permute(1, 2, 0).cpu().numpy() * 255).astype("uint8")
         if self.intro_last_frame is not None and not self.intro_transition_done:
             if self.video_writer is not None and vc.intro_enabled:
                 append_crossfade(self.video_writer, self.intro_last_frame, frame, self.intro_crossfade_frames)

@@ -88,7 +88,7 @@ def save_outputs(input_img: torch.Tensor, loss_metrics: LossHistory, output_dir:
         output_dir.mkdir(exist_ok=True)
         logger.info("Using fallback directory: %s", output_dir)
     final_path = stylized_image_path_from_names(output_dir, opts.content_name, opts.style_name)
-    image_io.save_image(image_io.prepare_image_for_output(input_img, normalize=opts.normalize), final_path)
+    image_io.save_image(input_img, final_path, normalize=opts.normalize)
     if opts.video_created and opts.video_name:
         logger.info("Video saved to: %s", output_dir / opts.video_name)
     if opts.plot_losses and loss_metrics:

@@ -133,3 +133,64 @@ def test_schedule_handles_taps_on_relu_and_pool_outputs():
     assert [t.buf is s.nodes[i].dst for t, i in zip(s.content_taps, (1, 3))] == [True] * 2
     with pytest.raises(RuntimeError, match="has a HIP kernel"):
         plan.Schedule([nn.Conv2d(3, 4, 5, padding=2)], [0], [], 8, 8, torch.float32, CPU, with_grad=False)
+
+
+# ----------------------------------------------------------------------------------------------
+# initialize_vgg: the pretrained-checkpoint branch (reference core_model.py:103-117).  The real
+# vgg19-dcbb9e9d.pth cannot be fetched here, so a checkpoint with the same key layout
+# (torchvision's `features.<idx>.weight/bias` + `classifier.*`) is fabricated in a temporary
+# torch.hub directory; torchvision itself is absent, which is exactly the branch under test.
+def _fake_checkpoint(path, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    state = {}
+    idx, cin = 0, 3
+    for v in synthetic.VGG19_CFG:
+        if v == "M":
+            idx += 1
+            continue
+        state[f"features.{idx}.weight"] = torch.randn(int(v), cin, 3, 3, generator=g) * 0.05
+        state[f"features.{idx}.bias"] = torch.randn(int(v), generator=g) * 0.1
+        cin = int(v)
+        idx += 2
+    state["classifier.0.weight"] = torch.zeros(4, 4)          # present in the real file, must be ignored
+    state["classifier.0.bias"] = torch.zeros(4)
+    path.parent.mkdir(parents=True, exist_ok=True)
+    torch.save(state, path)
+    return state
+
+
+def test_initialize_vgg_loads_cached_checkpoint(tmp_path, monkeypatch, caplog):
+    import logging
+    import sys
+    monkeypatch.delenv("STV_SYNTHETIC_WEIGHTS", raising=False)
+    monkeypatch.setitem(sys.modules, "torchvision", None)         # import torchvision -> ImportError
+    monkeypatch.setitem(sys.modules, "torchvision.models", None)
+    old_hub = torch.hub.get_dir()
+    torch.hub.set_dir(str(tmp_path / "hub"))
+    try:
+        ckpt = tmp_path / "hub" / "checkpoints" / "vgg19-dcbb9e9d.pth"
+        # cache miss without torchvision: a clear error, not a download attempt
+        with pytest.raises(RuntimeError, match="vgg19-dcbb9e9d.pth is absent"):
+            core_model.initialize_vgg()
+        state = _fake_checkpoint(ckpt)
+        lg = logging.getLogger("style_transfer")
+        lg.addHandler(caplog.handler)
+        try:
+            with caplog.at_level(logging.INFO, logger="style_transfer"):
+                vgg = core_model.initialize_vgg()
+        finally:
+            lg.removeHandler(caplog.handler)
+        assert any("Using cached VGG19 weights at" in r.getMessage() for r in caplog.records)
+    finally:
+        torch.hub.set_dir(old_hub)
+    assert not vgg.training and all(not p.requires_grad for p in vgg.parameters())
+    convs = [(i, l) for i, l in enumerate(vgg) if isinstance(l, nn.Conv2d)]
+    assert len(convs) == 16 and len(vgg) == 37              # torchvision vgg19().features layout
+    for i, conv in convs:
+        assert torch.equal(conv.weight, state[f"features.{i}.weight"])
+        assert torch.equal(conv.bias, state[f"features.{i}.bias"])
+    # and it slices like the reference's default layers
+    monkeypatch.setattr(core_model, "initialize_vgg", lambda: vgg)
+    model = core_model.StyleContentModel([0, 5, 10, 19, 28], [21])
+    assert len(model.vgg_blocks) == 6 and model.style_ids == [0, 1, 2, 3, 5] and model.content_ids == [4]
+    assert torch.equal(model.vgg_blocks[1][4].weight, state["features.5.weight"])
