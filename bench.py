@@ -118,18 +118,22 @@ def forward_bytes(sched, dtype_bytes: int) -> float:
     return total
 
 
-def run_gpu(args, rank: int, world: int, device: torch.device, size: int, steps: int, warmup: int):
+def run_gpu(args, rank: int, world: int, device: torch.device, size: int, steps: int, warmup: int, *,
+            precision: str | None = None, profile: bool = True):
+    """One L-BFGS run of `warmup` untimed + `steps` timed optimisation steps through the real
+    OptimizationRunner; returns elapsed seconds of the timed region (+ the kernel breakdown on rank 0)."""
     import torch.distributed as dist
 
     from style_transfer_visualizer_amd import _lib, config as stv_config
     from style_transfer_visualizer_amd import core_model, optimization, synthetic
 
+    precision = precision or args.precision
     os.environ.setdefault("STV_SYNTHETIC_WEIGHTS", "0")
     cfg = stv_config.StyleTransferConfig.model_validate({})
     oc = cfg.optimization
     oc.steps = warmup + steps
     oc.init_method = "random"
-    cfg.hardware.precision = args.precision
+    cfg.hardware.precision = precision
     cfg.video.create_video = False
     cfg.video.final_only = True
     cfg.output.log_every = 10
@@ -137,7 +141,7 @@ def run_gpu(args, rank: int, world: int, device: torch.device, size: int, steps:
     torch.cuda.manual_seed_all(oc.seed + rank)
     content = synthetic.synthetic_image(2 * rank, size, size).to(device)
     style = synthetic.synthetic_image(2 * rank + 1, size, size).to(device)
-    model, x, opt = core_model.prepare_model_and_input(content, style, device, oc, precision=args.precision)
+    model, x, opt = core_model.prepare_model_and_input(content, style, device, oc, precision=precision)
     torch.cuda.synchronize(device)
 
     marks = {}
@@ -163,18 +167,18 @@ def run_gpu(args, rank: int, world: int, device: torch.device, size: int, steps:
     out, _history, _ = runner.run()
     elapsed = marks["t1"] - marks["t0"]
     if world > 1:
+        from style_transfer_visualizer_amd import parallel
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        # the only collective of the job: gather the independent results (RCCL over xGMI)
-        gathered = [torch.empty_like(out.detach()) for _ in range(world)]
-        dist.all_gather(gathered, out.detach().contiguous())
-        assert len(gathered) == world
+        # the only data collective of the job: gather the independent results (RCCL over xGMI)
+        gathered = parallel.gather_results([(rank, out.detach().contiguous())], world)
+        assert len(gathered) == world and all(g is not None for g in gathered)
 
     info = {"elapsed": elapsed}
     st = opt.device_state() if hasattr(opt, "device_state") else {}
     info["lbfgs"] = {k: st.get(k) for k in ("n_iter", "hist_len", "skip", "no_update")}
-    if rank == 0:
+    if rank == 0 and profile:
         # per-op device time of the fused step (HIP events on the launch stream), 3 passes
         eng = next(iter(model._engines.values()))
         prog = next(p for k, p in eng._programs.items() if k[0] == "fused")
@@ -202,7 +206,7 @@ def run_gpu(args, rank: int, world: int, device: torch.device, size: int, steps:
         ms = [sum(p[i] for p in passes) / len(passes) for i in range(prog.n_ops)]
         groups: dict = {}
         for meta, t in zip(prog.op_meta, ms, strict=True):
-            g = kernel_group(meta, OP, 1 if args.precision == "bf16" else 0)
+            g = kernel_group(meta, OP, 1 if precision == "bf16" else 0)
             e = groups.setdefault(g, {"ms": 0.0, "flops": 0.0, "launches": 0})
             e["ms"] += t
             e["launches"] += 1
@@ -211,15 +215,15 @@ def run_gpu(args, rank: int, world: int, device: torch.device, size: int, steps:
         if args.per_op:
             names = {v: k for k, v in OP.items()}
             with open(args.per_op, "a") as f:
-                f.write(f"# size {size} precision {args.precision}\n")
+                f.write(f"# size {size} precision {precision}\n")
                 for meta, t in zip(prog.op_meta, ms, strict=True):
                     fl = conv_flops(meta) if meta[0] == OP["CONV"] else 0.0
                     f.write(f"{names.get(meta[0], meta[0]):18s} H{meta[1]:5d} W{meta[2]:5d} cin{meta[3]:4d} cout{meta[4]:4d} "
                             f"taps{meta[5]} n{meta[6]:9d}  {t * 1e3:9.1f} us  {fl / (t * 1e-3) / 1e12 if t > 0 else 0:8.1f} TF/s\n")
         dom_name, dom = max(groups.items(), key=lambda kv: kv[1]["ms"])
-        peak = BF16_PEAK_TFLOPS if args.precision == "bf16" else FP32_PEAK_TFLOPS
+        peak = BF16_PEAK_TFLOPS if precision == "bf16" else FP32_PEAK_TFLOPS
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
-        traffic, traffic_src = pmc_traffic(dom_name, size) if args.precision == "bf16" else (None, None)
+        traffic, traffic_src = pmc_traffic(dom_name, size) if precision == "bf16" else (None, None)
         info["roofline"] = {
             "bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": peak,
             "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -230,7 +234,7 @@ def run_gpu(args, rank: int, world: int, device: torch.device, size: int, steps:
         # (timed in context above: replays of the forward-only program; the per-op pass below runs
         # every kernel 8x on cache-hot operands and is only used to rank and rate kernels)
         fwd_gram_ms = fwd_gram_ctx_ms
-        dtype_bytes = 2 if args.precision == "bf16" else 4
+        dtype_bytes = 2 if precision == "bf16" else 4
         b_fwd = forward_bytes(eng.sched, dtype_bytes)
         total_flops = sum(e["flops"] for e in groups.values())
         step_ms = closure_ms
@@ -297,7 +301,8 @@ def cpu_baseline(size: int, threads: int) -> dict:
     def closure():
         _s, _c, t, g = ocm.loss_and_grad(model, x, 1e5, 1.0)
         return t, g
-    warm, timed = 2, (24 if size <= 512 else 6)     # ~10-15 s of CPU work at 512^2 on 16 cores
+    # ~10-15 s of CPU work per size on 16 cores (256^2: ~8 steps/s, 512^2: ~2, 1024^2: ~0.4)
+    warm, timed = {256: (2, 60), 512: (2, 24)}.get(size, (1, 5))
     for _ in range(warm):
         opt.step(closure)
     t0 = time.perf_counter()
@@ -308,6 +313,26 @@ def cpu_baseline(size: int, threads: int) -> dict:
             "sample": f"{size}x{size} VGG19 fp32, torch-CPU oracle, {warm} warm-up + {timed} timed L-BFGS steps"}
 
 
+STEADY_FILL, STEADY_STEPS = 100, 60        # history_size = 100: after 100 steps every step runs at m = 100
+
+
+def steady_state(args, device: torch.device, size: int, precision: str) -> dict:
+    """Throughput of the CONFIG, not of the ramp: BASELINE configs[1]/[2] are 300/500-step runs, so
+    >= 2/3 of their steps see a full L-BFGS history (m = 100) whatever --steps/--warmup the caller
+    chose for the headline line.  Fills the history with STEADY_FILL untimed steps, times STEADY_STEPS."""
+    e = run_gpu(args, 0, 1, device, size, STEADY_STEPS, STEADY_FILL, precision=precision, profile=False)
+    return {"steps_per_s": round(STEADY_STEPS / e["elapsed"], 2), "ms_per_step": round(1e3 * e["elapsed"] / STEADY_STEPS, 4),
+            "hist_len": e["lbfgs"].get("hist_len"), "fill_steps": STEADY_FILL, "timed_steps": STEADY_STEPS,
+            "precision": precision}
+
+
+def _free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return int(sk.getsockname()[1])
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -316,7 +341,8 @@ def main() -> None:
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the additional 1024x1024 measurement")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the additional legs (1024x1024, steady state at m=100, fp32 parity mode)")
     ap.add_argument("--per-op", default=None, help="append a per-op device-time table to this file")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only to rehearse N>1 on a single GPU")
@@ -325,21 +351,27 @@ def main() -> None:
                     help="BASELINE configs[4] instead: one 3840x2160 image, Adam, row strips over the N GPUs")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    # --gpus N without a launcher: start the N ranks ourselves, as CHILD processes, before this
+    # process has touched the GPU (never exec from a process that has initialised HIP).
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+        sys.exit(subprocess.run(cmd, check=False).returncode)
+
+    from style_transfer_visualizer_amd import parallel
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus:
+        print(json.dumps({"error": f"--gpus {args.gpus} does not match WORLD_SIZE={world_env}: launch with "
+                                   f"`python bench.py --gpus N` (spawns the ranks) or torchrun --nproc-per-node N"}))
+        sys.exit(2)
     if not torch.cuda.is_available():
         print(json.dumps({"error": "no GPU: the HIP hot path has no CPU fallback"}))
         sys.exit(2)
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     device = torch.device("cuda", 0 if args.share_gpu else local_rank)
     torch.cuda.set_device(device)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+    rank, _, world = parallel.init_distributed(args.dist_backend, device=device)
 
     if args.spatial:
         info = run_spatial(args, rank, world, device)
@@ -350,17 +382,15 @@ def main() -> None:
                 "ms_per_step": round(1e3 * info["elapsed"] / args.steps, 3), "higher_is_better": True,
                 "scaling": "strong", "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32",
                 "data": "synthetic",
-                "config": {"workload": "single 3840x2160 image, Adam lr 1e-3, VGG19, row-strip partition with "
-                                       "recomputed 160-row halos (BASELINE.json configs[4])",
+                "config": {"workload": "single 3840x2160 image, Adam lr 1e-3, VGG19, row-strip partition "
+                                       f"({info.get('mode', 'recomputed halos')}; BASELINE.json configs[4])",
                            "parallelism": f"spatial x{world}", "rank0_rows": info["rows"]},
                 "scores": info["scores"]}))
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-            dist.destroy_process_group()
+        parallel.shutdown()
         return
     info = run_gpu(args, rank, world, device, args.size, args.steps, args.warmup)
     extra = None
+    steady = None
     if not args.no_extra and args.size == 512 and world == 1:
         k2, w2 = max(10, args.steps // 4), max(5, min(args.warmup, 100))
         e = run_gpu(args, rank, world, device, 1024, k2, w2)
@@ -368,6 +398,11 @@ def main() -> None:
                  "value": round(k2 / e["elapsed"], 3), "ms_per_step": round(1e3 * e["elapsed"] / k2, 4),
                  "roofline": e.get("roofline"), "fwd_gram": e.get("fwd_gram"), "closure": e.get("closure"),
                  "breakdown_ms": e.get("breakdown_ms"), "lbfgs": e.get("lbfgs")}
+        steady = {"note": ("throughput with the L-BFGS history full (m = 100), independent of --steps/--warmup: "
+                           f"{STEADY_FILL} untimed fill steps, then {STEADY_STEPS} timed steps through OptimizationRunner"),
+                  "512x512_bf16": steady_state(args, device, 512, "bf16"),
+                  "1024x1024_bf16": steady_state(args, device, 1024, "bf16"),
+                  "512x512_fp32_parity_mode": steady_state(args, device, 512, "fp32")}
 
     if rank == 0:
         total_steps = args.steps * world
@@ -397,16 +432,18 @@ def main() -> None:
             "breakdown_ms": info.get("breakdown_ms"),
             "lbfgs": info.get("lbfgs"),
         }
+        if steady is not None:
+            line["steady_state"] = steady
         if extra is not None:
             line["extra_1024"] = extra
         if world == 1 and not args.no_cpu_baseline:
             threads = max(1, min(os.cpu_count() or 1, 16))
             line["cpu_baseline"] = cpu_baseline(args.size, threads)
+            if not args.no_extra and args.size == 512:      # the other two sizes beside it
+                line["cpu_baseline_other_sizes"] = {"256x256": cpu_baseline(256, threads),
+                                                    "1024x1024": cpu_baseline(1024, threads)}
         print(json.dumps(line))
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
-        dist.destroy_process_group()
+    parallel.shutdown()
 
 
 if __name__ == "__main__":

@@ -72,6 +72,47 @@ class _RoundBf16(torch.autograd.Function):
         return g.bfloat16().to(g.dtype)
 
 
+class _GradRoundBf16(torch.autograd.Function):
+    """Identity going forward; rounds the gradient to bf16 coming back.  Marks a point where the
+    build's backward pass stores a partial gradient sum (bf16) before another term is added."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().to(g.dtype)
+
+
+class _StyleLossBf16Seed(torch.autograd.Function):
+    """mse(gram(F), T) whose backward is dF = F . bf16(S): the build's Gram finish kernel stores
+    the symmetric seed S = gout * 4/(C^2 * norm) * [R <= clamp] * (G - T) in bf16 before the
+    1x1 product (csrc/gram.hip gram_finish_body).  Forward value = the plain fp32 arithmetic."""
+
+    @staticmethod
+    def forward(ctx, f4d, target, clamp_max):
+        b, c, h, w = f4d.shape
+        C, n = b * c, h * w
+        f = f4d.reshape(C, n)
+        raw = torch.mm(f, f.t())
+        norm = float(C * n)
+        g = raw.clamp(max=clamp_max) / norm
+        ctx.save_for_backward(f, g - target, raw <= clamp_max)
+        ctx.meta = (f4d.shape, norm)
+        return F.mse_loss(g, target)
+
+    @staticmethod
+    def backward(ctx, gout):
+        f, diff, keep = ctx.saved_tensors
+        shape, norm = ctx.meta
+        C = f.shape[0]
+        k = torch.tensor(float(gout), dtype=torch.float32) * 4.0 / (float(C) * float(C) * norm)   # fp32, as the host computes it
+        seed = torch.where(keep, k.to(diff.dtype) * diff, torch.zeros_like(diff))
+        seed = seed.bfloat16().to(f.dtype)
+        return torch.mm(seed, f).reshape(shape), None, None
+
+
 def gram_matrix(t: torch.Tensor, clamp_max: float = GRAM_CLAMP_MAX) -> torch.Tensor:
     """core_model.py:29-63: clamp(F F^T, max) / (b*c*h*w), batch folded in."""
     b, c, h, w = t.shape
@@ -115,12 +156,19 @@ class OracleModel:
         content_layers: Sequence[int],
         *,
         bf16_storage: bool = False,
+        fused_style_taps: Sequence[int] | None = None,
     ) -> None:
-        """``bf16_storage`` emulates the build's performance mode on the CPU: conv weights (except
-        the first layer's) and every stored activation / activation gradient are rounded to bf16,
-        all arithmetic stays fp32.  It is NOT the reference's arithmetic; it exists to tell bf16
-        rounding effects from kernel bugs."""
+        """``bf16_storage`` emulates the build's performance mode on the CPU, rounding exactly where
+        the kernels round: conv weights (except the first layer's, which stays fp32), every stored
+        activation, every stored activation gradient (including the partial sum a buffer holds
+        between its consumer's dgrad and a loss tap's accumulate), and the Gram backward seed S;
+        all arithmetic stays fp32.  ``fused_style_taps``: orders (0-based, block order) of the style
+        taps whose Gram-backward term rides in the consumer's dgrad (one rounding of the sum
+        instead of two; ``stv_conv_igemm_dual``) - default: every style tap that has a consumer.
+        It is NOT the reference's arithmetic; it exists to tell bf16 rounding effects from kernel
+        bugs."""
         self.bf16_storage = bf16_storage
+        self.fused_style_taps = None if fused_style_taps is None else set(fused_style_taps)
         self.program = list(program)
         if bf16_storage:
             seen_conv = False
@@ -164,6 +212,8 @@ class OracleModel:
             msg = "content_targets must be set before computing losses."
             raise RuntimeError(msg)
         style_losses, content_losses = [], []
+        if self.bf16_storage:
+            return self._call_bf16(x)
         feats = self._features(x)
         for j, f in enumerate(feats):
             if j in self.style_ids:
@@ -172,6 +222,51 @@ class OracleModel:
             if j in self.content_ids:
                 tgt = self.content_targets[self.content_ids.index(j)]
                 content_losses.append(F.mse_loss(f, tgt))
+        return style_losses, content_losses
+
+    def _call_bf16(self, x: torch.Tensor) -> tuple[list[torch.Tensor], list[torch.Tensor]]:
+        """Same losses with the build's bf16 rounding points (see ``__init__``).  Backward order at a
+        tapped buffer, as style_transfer_visualizer_amd/plan.py emits it: the consumer's dgrad
+        writes the buffer's gradient first (a fused style tap's F.S added before that one
+        rounding), then the remaining taps accumulate one by one, style before content, each with
+        its own rounding."""
+        style_losses, content_losses = [], []
+        last = len(self.blocks) - 1
+        for j, blk in enumerate(self.blocks):
+            for li in blk:
+                x = run_layer(self.program[li], x)
+                if self.program[li][0] in ("conv", "pool"):
+                    x = _RoundBf16.apply(x)
+            k_style = self.style_ids.index(j) if j in self.style_ids else None
+            has_consumer = j < last
+            fused = (k_style is not None and has_consumer
+                     and (self.fused_style_taps is None or k_style in self.fused_style_taps))
+            taps = []                                     # in the order the plan accumulates them
+            if k_style is not None and not fused:
+                taps.append("style")
+            if j in self.content_ids:
+                taps.append("content")
+            # node chain: y[0] = x (its backward rounds the final sum), y[k+1] = y[k] with a rounding
+            # of the gradient in between.  The consumer and a fused tap read the deepest node; the
+            # i-th tap reads node len(taps)-1-i, so its term lands on the already-rounded partial sum.
+            # (Without a consumer the first tap writes instead of accumulating: one node fewer.)
+            nodes = [x]
+            for _ in range(len(taps) if has_consumer else max(len(taps) - 1, 0)):
+                nodes.append(_GradRoundBf16.apply(nodes[-1]))
+            deepest = nodes[-1]
+
+            def style_term(src):
+                return _StyleLossBf16Seed.apply(src, self.style_targets[k_style], GRAM_CLAMP_MAX)
+            if fused:
+                style_losses.append(style_term(deepest))
+            for i, kind in enumerate(taps):
+                src = nodes[len(taps) - 1 - i]
+                if kind == "style":
+                    style_losses.append(style_term(src))
+                else:
+                    tgt = self.content_targets[self.content_ids.index(j)]
+                    content_losses.append(F.mse_loss(src, tgt))
+            x = deepest
         return style_losses, content_losses
 
 

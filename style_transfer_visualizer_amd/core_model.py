@@ -305,9 +305,20 @@ class _Engine:
         if prog is None:
             if len(self._programs) >= 16:     # programs are keyed by buffer addresses: bound the cache (oldest out)
                 self._programs.pop(next(iter(self._programs)))
-            prog = plan.Program(builder(), self.sched._keep)
+            prog = self._build(self.sched, builder)
             self._programs[key] = prog
         return prog
+
+    @staticmethod
+    def _build(sched: plan.Schedule, builder, extra: tuple = ()) -> plan.Program:
+        """Program from ``builder()``'s ops, owning exactly the tensors those ops reference by raw
+        pointer (the schedule's keep-alive list is restored: it must not grow with every program,
+        or every image ever evaluated would stay allocated)."""
+        base = len(sched._keep)
+        op_list = builder()
+        keep = sched._keep[base:] + list(extra)
+        del sched._keep[base:]
+        return plan.Program(op_list, keep)
 
     # -- targets ---------------------------------------------------------------
     def stage_input(self, x: torch.Tensor) -> torch.Tensor:
@@ -325,7 +336,7 @@ class _Engine:
     def capture_content(self, content_img: torch.Tensor) -> list[torch.Tensor]:
         self.generation += 1
         x = content_img.detach().contiguous().float()
-        plan.Program(self.sched.forward_ops(x), self.sched._keep + [x]).run()
+        self._build(self.sched, lambda: self.sched.forward_ops(x), (x,)).run()
         targets = [tap.buf.act.clone() for tap in self.sched.content_taps]
         for tap, t in zip(self.sched.content_taps, targets, strict=True):
             tap.target = t
@@ -338,14 +349,17 @@ class _Engine:
         sched = (self.sched if (Hs, Ws) == (self.H, self.W) else
                  plan.Schedule(self.layers, self.style_at, self.content_at, Hs, Ws, self.dtype, self.device,
                                with_grad=False))
-        op_list = sched.forward_ops(x)
         grams = []
-        for tap in sched.style_taps:
-            g = torch.empty(tap.buf.C, tap.buf.C, device=self.device, dtype=torch.float32)
-            grams.append(g)
-            op_list += sched.gram_ops(tap, gram_out=g, target=None, loss_part=None, sgrad=None, coef=0.0,
-                                      coef_dev=None)
-        plan.Program(op_list, sched._keep + [x]).run()
+
+        def build():
+            op_list = sched.forward_ops(x)
+            for tap in sched.style_taps:
+                g = torch.empty(tap.buf.C, tap.buf.C, device=self.device, dtype=torch.float32)
+                grams.append(g)
+                op_list += sched.gram_ops(tap, gram_out=g, target=None, loss_part=None, sgrad=None, coef=0.0,
+                                          coef_dev=None)
+            return op_list
+        self._build(sched, build, (x, sched)).run()
         for tap, g in zip(self.sched.style_taps, grams, strict=True):
             tap.target = g
         return grams

@@ -16,8 +16,11 @@ import torch
 import torch.distributed as dist
 
 
-def init_distributed(backend: str | None = None) -> tuple[int, int, int]:
-    """Initialise from the torchrun environment; returns (rank, local_rank, world_size)."""
+def init_distributed(backend: str | None = None, *, device: torch.device | None = None) -> tuple[int, int, int]:
+    """Initialise from the torchrun environment; returns (rank, local_rank, world_size).
+
+    ``device``: the GPU this rank drives (default ``cuda:LOCAL_RANK``); only used to bind the
+    RCCL communicator ("nccl" backend)."""
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -28,9 +31,16 @@ def init_distributed(backend: str | None = None) -> tuple[int, int, int]:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         kwargs = {}
         if backend == "nccl":
-            kwargs["device_id"] = torch.device("cuda", local_rank)
+            kwargs["device_id"] = device if device is not None else torch.device("cuda", local_rank)
         dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
     return rank, local_rank, world
+
+
+def shutdown() -> None:
+    """Barrier + destroy the process group (no-op for a single process)."""
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def shard_items(n_items: int, rank: int, world: int) -> list[int]:

@@ -1,0 +1,189 @@
+"""Parity at the REAL sizes of BASELINE.json configs[1] (512x512) and configs[2] (1024x1024):
+full-width VGG19, the benchmark's synthetic weights/images (bench.py seeds), default layers and
+weights - what only exists at full size (the tile configurations picked there, Gram split-K over
+2.6e5..1e6 pixels, the batched Gram chain's 48-MiB decision, fused conv+pool on 1024-wide rows).
+
+Per size and precision: the five Gram targets, then one closure + three L-BFGS steps with the CPU
+oracle re-evaluated AT THE SAME IMAGE every step (chaos-free: reference optimization.py:286-327,
+core_model.py:297-328), and the device L-BFGS update against the oracle optimizer fed the same
+gradients.  fp32 = the parity mode (reference arithmetic); bf16 = the measured mode, against the
+oracle that rounds to bf16 exactly where the kernels do (oracle/core_model_ref.py).
+
+Tolerances (measured values are printed in the parity table at the end of the run):
+* fp32: losses 1e-5 relative; gradient 2e-4 of its max-abs scale per pixel.  ReLU / max-pool
+  decisions that flip between two correct fp32 evaluations (|z| within rounding of 0) change the
+  gradient locally by more than rounding, on both sides alike; pixels beyond the bound are counted
+  and must stay below 1e-5 of all pixels, and the rms error below 5e-5 of scale.
+* bf16: losses 2e-3 relative (bf16 has 8 mantissa bits: one differently-rounded activation is
+  2^-9 of its value); gradient rms 1e-2 of the gradient's rms - the emulation rounds at the same
+  points, what remains are roundings that fall differently because fp32 sums are ordered
+  differently (a bf16 tie flips a value by 2^-8), amplified through 13 layers.
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import core_model_ref as ocm
+from oracle import optim_ref
+from style_transfer_visualizer_amd import _lib, core_model, ops, synthetic
+from tests.conftest import record_parity
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda")
+S_LAYERS, C_LAYERS = [0, 5, 10, 19, 28], [21]
+STYLE_W, CONTENT_W = 1e5, 1.0
+
+
+def _fused_style_taps(model) -> list[int]:
+    """Orders of the style taps whose Gram-backward term the plan fused into a dgrad launch."""
+    eng = next(iter(model._engines.values()))
+    prog = next(p for k, p in eng._programs.items() if k[0] == "fused")
+    dual = {(H, W, cout) for (op, H, W, cin, cout, taps, n) in prog.op_meta
+            if op == _lib.OP_CONV and taps == 9 and n > 0}
+    return [t.order for t in eng.sched.style_taps if (t.buf.H, t.buf.W, t.buf.C) in dual]
+
+
+def _grad_stats(g: torch.Tensor, g_ref: torch.Tensor, bound: float) -> tuple[float, float, float]:
+    scale = float(g_ref.abs().max())
+    err = (g - g_ref).abs() / scale
+    return float(err.max()), float(err.pow(2).mean().sqrt()), float((err > bound).float().mean())
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("size", [512, 1024])
+def test_fullsize_closure_and_lbfgs_steps_match_oracle(size, precision, monkeypatch):
+    monkeypatch.setenv("STV_SYNTHETIC_WEIGHTS", "0")
+    case = f"vgg19_{size}x{size}_{precision}"
+    weights = synthetic.synthetic_conv_weights(0)
+    content = synthetic.synthetic_image(0, size, size)
+    style = synthetic.synthetic_image(1, size, size)
+    x0 = torch.randn(content.shape, generator=torch.Generator().manual_seed(0))      # init_method=random, as bench.py
+
+    # ---- HIP path: pinned tiles (STV_CONV_TUNE=0, the conftest default) and measured tiles --------
+    def hip_model(tune: str):
+        monkeypatch.setenv("STV_CONV_TUNE", tune)
+        model = core_model.StyleContentModel(S_LAYERS, C_LAYERS, precision=precision).to(DEV)
+        model.set_targets(style.to(DEV), content.to(DEV))
+        x = x0.to(DEV).clone().requires_grad_(True)
+        s, c, t = model.loss_and_grad(x, STYLE_W, CONTENT_W)
+        return model, x, (float(s), float(c), float(t)), x.grad.detach().cpu().clone()
+    model, x, l_pin, g_pin = hip_model("0")
+    fused = _fused_style_taps(model)
+    model_t, x_t, l_tun, g_tun = hip_model("1")
+    tiles = {"pinned": [], "tuned": []}
+    monkeypatch.setenv("STV_CONV_TUNE", "0")
+    eng = next(iter(model._engines.values()))
+    dcode = ops.dtype_code(eng.dtype)
+    for nd in eng.sched.nodes:
+        if nd.kind == "conv":
+            tiles["pinned"].append(int(_lib.load().stv_conv_config(nd.dst.H, nd.dst.W, nd.cin, nd.dst.C, 9, dcode)))
+    monkeypatch.setenv("STV_CONV_TUNE", "1")
+    for nd in eng.sched.nodes:
+        if nd.kind == "conv":
+            tiles["tuned"].append(int(_lib.load().stv_conv_config(nd.dst.H, nd.dst.W, nd.cin, nd.dst.C, 9, dcode)))
+    print(f"{case}: forward tiles pinned {tiles['pinned']} tuned {tiles['tuned']}; fused style taps {fused}")
+
+    # ---- oracle -------------------------------------------------------------------------------------
+    t0 = time.time()
+    bf16 = precision == "bf16"
+    oracle = ocm.OracleModel(ocm.vgg_program(weights, synthetic.VGG19_CFG), S_LAYERS, C_LAYERS,
+                             bf16_storage=bf16, fused_style_taps=fused if bf16 else None)
+    oracle.set_targets(style, content)
+    ltol, gmax_tol, grms_tol = (1e-5, 2e-4, 5e-5) if not bf16 else (2e-3, None, 1e-2)
+    for i, (tg, to) in enumerate(zip(model.style_targets, oracle.style_targets, strict=True)):
+        dev = float((tg.cpu() - to).abs().max() / to.abs().max())
+        record_parity(case, f"Gram target {i} (of max)", dev, 2e-4 if not bf16 else 2e-3)
+        assert dev <= (2e-4 if not bf16 else 2e-3)
+    ct, co = model.content_targets[0].float().cpu(), oracle.content_targets[0]
+    assert ct.shape == co.shape
+    dev = float((ct - co).abs().max() / co.abs().max())
+    record_parity(case, "content target (of max)", dev, 2e-5 if not bf16 else 8e-3)
+    assert dev <= (2e-5 if not bf16 else 8e-3)
+
+    def check(tag: str, losses, g, ref) -> None:
+        s_ref, c_ref, t_ref, g_ref = ref
+        for nm, got, want in (("style", losses[0], float(s_ref)), ("content", losses[1], float(c_ref)),
+                              ("total", losses[2], float(t_ref))):
+            rel = abs(got - want) / abs(want)
+            record_parity(case, f"{tag} {nm} loss (rel)", rel, ltol)
+            assert rel <= ltol, f"{case} {tag}: {nm} loss {got!r} vs oracle {want!r}"
+        if not bf16:
+            mx, rms, frac = _grad_stats(g, g_ref, gmax_tol)
+            record_parity(case, f"{tag} grad rms (of max)", rms, grms_tol)
+            record_parity(case, f"{tag} grad max (of max)", mx, gmax_tol,
+                          f"{frac:.1e} of pixels over the bound (ReLU/pool near-tie flips); allowed 1e-5")
+            assert rms <= grms_tol and frac <= 1e-5, f"{case} {tag}: grad rms {rms:.2e}, max {mx:.2e}, frac>{gmax_tol:g}: {frac:.2e}"
+        else:
+            rel = float((g - g_ref).norm() / g_ref.norm())
+            record_parity(case, f"{tag} grad rms (of rms)", rel, grms_tol)
+            assert rel <= grms_tol, f"{case} {tag}: bf16 gradient differs from the rounding-faithful oracle by {rel:.2e}"
+
+    ref0 = ocm.loss_and_grad(oracle, x0, STYLE_W, CONTENT_W)
+    check("step1 pinned-tiles", l_pin, g_pin, ref0)
+    check("step1 tuned-tiles", l_tun, g_tun, ref0)
+    del model_t, x_t
+
+    # ---- three L-BFGS steps: oracle at the same image, oracle optimizer fed the HIP gradients --------
+    x_twin = x.detach().cpu().clone()
+    twin = optim_ref.LbfgsRef(x_twin.view(-1), lr=1.0)
+    state, work = ops.lbfgs_alloc(x.numel(), 100, DEV, compact=True)
+    losses, g = l_pin, g_pin
+    for step in range(1, 4):
+        t_dev = torch.tensor(losses[2])
+        twin.step(lambda: (t_dev, g))
+        ops.lbfgs_step(x.detach(), x.grad, state, work, 100, min(step - 1, 100), 1.0, compact=True)
+        drift = float((x.detach().cpu() - x_twin).abs().max() / x_twin.abs().max())
+        record_parity(case, f"L-BFGS update {step} vs oracle optimizer", drift, 5e-6)
+        assert drift <= 5e-6
+        s, c, t = model.loss_and_grad(x, STYLE_W, CONTENT_W)
+        losses, g = (float(s), float(c), float(t)), x.grad.detach().cpu().clone()
+        check(f"step{step + 1}", losses, g, ocm.loss_and_grad(oracle, x.detach().cpu(), STYLE_W, CONTENT_W))
+    print(f"{case}: oracle time {time.time() - t0:.0f} s")
+    del model, x
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("n_pixels,C", [(2 ** 18, 64), (2 ** 18, 128), (2 ** 18, 512), (2 ** 20, 64), (2 ** 20, 128),
+                                        (2 ** 20, 256)])
+def test_gram_chain_at_full_pixel_counts(n_pixels, C, precision):
+    """stv_gram_partial / stv_gram_finish called directly at the pixel counts of the 512^2 / 1024^2
+    nets (split-K over 2^18 and 2^20 pixels), clamp engaged, vs the oracle's gram_matrix / MSE /
+    seed arithmetic in float64."""
+    dtype = torch.float32 if precision == "fp32" else torch.bfloat16
+    g = torch.Generator().manual_seed(n_pixels // 1024 + C)
+    side = int(n_pixels ** 0.5)
+    feat = (torch.randn(n_pixels, C, generator=g) * 0.7 + 0.1).to(dtype)        # NHWC rows = pixels
+    f64 = feat.double()
+    raw = f64.t() @ f64
+    clamp = float(raw.diagonal().median())                                       # engages on part of the diagonal
+    norm = float(C * n_pixels)
+    gram_ref = raw.clamp(max=clamp) / norm
+    target = (gram_ref * 0.9).float()
+    fd = feat.to(DEV).reshape(side, side, C)
+    partials = ops.gram_partial(fd)
+    gram = torch.empty(C, C, device=DEV)
+    parts = torch.zeros(ops.gram_loss_parts(C), device=DEV)
+    seed = torch.empty(C, C, device=DEV, dtype=dtype)
+    ops.gram_finish(partials, n_pixels, C, target=target.to(DEV), gram_out=gram, loss_part=parts, sgrad=seed,
+                    clamp_max=clamp, coef=STYLE_W, dtype=dtype)
+    case = f"gram n={n_pixels} C={C} {precision}"
+    tol = 2e-5
+    dev = float((gram.cpu().double() - gram_ref).abs().max() / gram_ref.abs().max())
+    record_parity(case, "G (of max)", dev, tol)
+    assert dev <= tol
+    loss = float(parts.double().sum().cpu()) / (C * C)
+    loss_ref = float(((gram_ref - target.double()) ** 2).mean())
+    record_parity(case, "mse loss (rel)", abs(loss - loss_ref) / loss_ref, 1e-4)
+    assert loss == pytest.approx(loss_ref, rel=1e-4)
+    seed_ref = STYLE_W * 4.0 / (C * C * norm) * (raw <= clamp) * (gram_ref - target.double())
+    # elements whose raw sum is within rounding of the clamp may fall on either side of it
+    near = (raw - clamp).abs() <= 1e-5 * clamp
+    sdev = ((seed.cpu().double() - seed_ref).abs() / seed_ref.abs().max()).masked_fill(near, 0.0)
+    stol = 1e-5 if precision == "fp32" else 2.0 ** -8
+    record_parity(case, "seed S (of max)", float(sdev.max()), stol)
+    assert float(sdev.max()) <= stol

@@ -14,7 +14,7 @@ import torch
 from oracle import core_model_ref as ocm
 from style_transfer_visualizer_amd import config as stv_config
 from style_transfer_visualizer_amd import core_model, optimization, optimizers, synthetic
-from tests.conftest import GoldenCase
+from tests.conftest import GoldenCase, record_parity
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda")
@@ -120,12 +120,19 @@ def test_trajectory_matches_reference(golden_case: GoldenCase, monkeypatch):
     upto = int(blown[0]) + 1 if len(blown) else steps
     xf = case.arrays["x_final"]
     dev = float(np.abs(out.detach().cpu().numpy() - xf).max() / np.abs(xf).max())
+    name = case.meta.get("name", request_name(case))
+    base_tol = ptol
+    probed = False
     if not len(blown) and dev > ptol:
         # The fixture's sensitivity was probed with 3e-7 gradient noise; two correct fp32
         # evaluations differ by more than that (summation order: ~1e-6).  Before calling the
         # deviation an error, measure what THIS path does to itself under a last-bit change of the
         # start image: a trajectory that amplifies one ulp to `self_dev` cannot be pinned tighter
         # than a small multiple of it.  A systematic error does not shrink under this probe.
+        # The widened window is CAPPED (1e-2 of the image range) and its use is recorded in the
+        # parity table; such a fixture must additionally match the reference on its first steps -
+        # before the amplification - at the plain 1e-4 (below).
+        probed = True
         _, model2, x2, opt2 = _build(case, monkeypatch)
         with torch.no_grad():
             g = torch.Generator().manual_seed(7)
@@ -134,8 +141,17 @@ def test_trajectory_matches_reference(golden_case: GoldenCase, monkeypatch):
             opt2 = optimizers.HipAdam([x2], lr=m["adam_lr"])
         out2, _, _ = optimization.OptimizationRunner(model2, x2, cfg, optimizer=opt2, progress_bar=_Bar()).run()
         self_dev = float((out2 - out).abs().max() / out.abs().max())
-        ptol = max(ptol, 10.0 * self_dev)      # one probe is a noisy estimate of the spread: leave a decade
+        ptol = min(max(ptol, 10.0 * self_dev), PROBE_TOL_CAP)      # one probe is a noisy estimate: a decade, capped
     ltol = max(1e-3, 10 * ptol)
+    # steps 1-2 are evaluated at x0 and x0 - t*g1: no curvature estimate involved yet, so every
+    # fixture - chaotic or not - must match the reference there at the plain 1e-4
+    first = min(2, upto)
+    dev_first = float(np.abs(np.asarray(history["total_loss"][:first]) / ref_total[:first] - 1.0).max())
+    record_parity(name, f"total loss, first {first} steps (rel)", dev_first, 1e-4)
+    np.testing.assert_allclose(history["total_loss"][:first], ref_total[:first], rtol=1e-4)
+    dev_loss = float(np.abs(np.asarray(history["total_loss"][:upto]) / ref_total[:upto] - 1.0).max())
+    record_parity(name, f"total loss, {upto} steps (rel)", dev_loss, ltol,
+                  "chaotic fixture: self-spread probe engaged" if probed else "")
     np.testing.assert_allclose(history["total_loss"][:upto], ref_total[:upto], rtol=ltol)
     # the two terms: relative, with an absolute floor of 1e-6 of the total for a weighted term that
     # is numerically negligible in it (the content loss of a content-initialised image is ~1e-5 of
@@ -144,7 +160,22 @@ def test_trajectory_matches_reference(golden_case: GoldenCase, monkeypatch):
         np.testing.assert_allclose(wgt * np.asarray(history[key][:upto]), wgt * case.arrays[key][:upto], rtol=ltol,
                                    atol=1e-6 * float(np.abs(ref_total[:upto]).max()))
     if not len(blown):
+        note = (f"1e-4 / fixture sensitivity gives {base_tol:.1e}; widened by the self-spread probe (cap {PROBE_TOL_CAP:g})"
+                if probed else ("meets north_star 1e-4 outright" if ptol <= 1e-4 else
+                                f"fixture sensitivity (reference's own spread) {ptol / 4:.1e} x4"))
+        record_parity(name, "x_final per pixel (of range)", dev, ptol, note)
         assert dev <= ptol, f"final image deviates by {dev:.2e} of its range (tolerance {ptol:.2e})"
+    else:
+        record_parity(name, "x_final per pixel (of range)", float("nan"), float("nan"),
+                      f"reference trajectory overshoots at step {upto}: compared up to there only")
+
+
+PROBE_TOL_CAP = 1e-2
+
+
+def request_name(case: GoldenCase) -> str:
+    m = case.meta
+    return f"{m.get('net', 'net')}_{m['init_method']}_{m['optimizer']}_{m['hw_content'][0]}x{m['hw_content'][1]}"
 
 
 def _decision_flips(model, oracle64, x64):
