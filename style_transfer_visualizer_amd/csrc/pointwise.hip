@@ -398,11 +398,18 @@ int pool_bwd_typed(const void* x, const void* dy, void* dx, int H, int W, int C,
 struct FrameStats { float mean[3], std[3]; };
 
 __device__ __forceinline__ uint32_t frame_u8(float v, float mean, float stdv, int normalize, int round) {
-  if (normalize) v = __fadd_rn(__fmul_rn(v, stdv), mean);      // no fma: torch does mul then add
+#pragma clang fp contract(off)      // torch evaluates mul and add as two ops: an fma here changes last bits -> other bytes
+  if (normalize) {
+    const float scaled = v * stdv;
+    v = scaled + mean;
+  }
   if (v != v) v = 0.0f;
   v = fminf(fmaxf(v, 0.0f), 1.0f);                               // +-inf land on 1 / 0 like nan_to_num + clamp
-  float s = __fmul_rn(v, 255.0f);
-  if (round) s = fminf(fmaxf(__fadd_rn(s, 0.5f), 0.0f), 255.0f);
+  float s = v * 255.0f;
+  if (round) {
+    const float r = s + 0.5f;
+    s = fminf(fmaxf(r, 0.0f), 255.0f);
+  }
   return (uint32_t)s;
 }
 
