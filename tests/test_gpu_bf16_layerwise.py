@@ -13,7 +13,8 @@ the loss by 6e-5 (tests/test_oracle_golden.py::test_bf16_storage_is_chaotic_unde
 So two CORRECT bf16 evaluations agree on the loss to ~1e-4 and on the gradient only to ~10 %:
 an end-to-end gradient tolerance cannot separate a wrong epilogue from rounding chaos, a per-op
 comparison on identical inputs can.  Bound asserted here for every stored tensor: each element
-within ONE bf16 ulp of the oracle's value, at most 2 % of the elements different at all (the
+within ONE bf16 ulp of the oracle's value (three where a loss tap accumulates onto an already rounded
+gradient: two roundings), at most 2 % of the elements different at all (the
 differences are roundings of fp32 sums that were accumulated in another order), pooling routes
 bit-exact.  Measured fractions are printed in the parity table.
 """
@@ -41,7 +42,7 @@ def _nchw(act: torch.Tensor) -> torch.Tensor:
     return act.detach().cpu().float().permute(2, 0, 1).unsqueeze(0).contiguous()
 
 
-def _compare(case: str, what: str, got: torch.Tensor, want: torch.Tensor, *, exact: bool = False) -> None:
+def _compare(case: str, what: str, got: torch.Tensor, want: torch.Tensor, *, exact: bool = False, ulps: float = 1.0) -> None:
     """`got`: what the kernel stored (bf16 values as fp32); `want`: bf16(oracle op on the same inputs)."""
     assert got.shape == want.shape, f"{what}: shape {tuple(got.shape)} vs {tuple(want.shape)}"
     diff = (got - want).abs()
@@ -53,9 +54,9 @@ def _compare(case: str, what: str, got: torch.Tensor, want: torch.Tensor, *, exa
     worst = float((diff / (2.0 ** -7 * scale + floor)).max())
     tol_frac = 0.0 if exact else 2e-2
     record_parity(case, f"{what}: fraction != oracle", frac, tol_frac,
-                  "bit-exact expected" if exact else f"largest difference {worst:.2f} of one bf16 ulp (bound 1)")
+                  "bit-exact expected" if exact else f"largest difference {worst:.2f} of one bf16 ulp (bound {ulps:g})")
     assert frac <= tol_frac, f"{case} {what}: {frac:.2e} of the elements differ"
-    assert worst <= 1.0, f"{case} {what}: an element is {worst:.2f} bf16 ulps from the oracle"
+    assert worst <= ulps, f"{case} {what}: an element is {worst:.2f} bf16 ulps from the oracle"
 
 
 @pytest.mark.parametrize("size", [512, 1024])
@@ -167,7 +168,12 @@ def test_bf16_every_stored_tensor_within_one_ulp_of_the_oracle_op(size, monkeypa
         if b.relu_fused and b.taps:
             g = g * (act > 0)
         exact = consumer is not None and consumer.kind != "conv" and not b.taps
-        _compare(case, f"bwd grad of L{nd.layer:02d} {nd.kind} out ({b.C}ch @{b.H})", _nchw(b.grad), g, exact=exact)
+        # a tap that ACCUMULATES onto the stored gradient rounds twice: a one-ulp difference of the first
+        # rounding survives into a sum that may be smaller than its terms -> up to ~1 ulp of the larger
+        # term plus one of the result
+        n_accum = sum(1 for t in b.taps if t is not fused_tap) - (1 if consumer is None else 0)
+        _compare(case, f"bwd grad of L{nd.layer:02d} {nd.kind} out ({b.C}ch @{b.H})", _nchw(b.grad), g, exact=exact,
+                 ulps=1.0 if n_accum <= 0 else 3.0)
 
     first = nodes[0]
     w, _ = weights_of(first)
