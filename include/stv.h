@@ -138,6 +138,12 @@ int stv_conv_igemm_dual(const void* x, const void* w, const void* x2, const void
  * 7 = 2x64 and 8 = 1x64 (four waves) with the K split. */
 int stv_conv_config(int H, int W, int cin, int cout, int taps, int dtype);
 
+/* 1 when stv_conv_igemm / _pool / _dual run this launch on the weight-stationary persistent kernel
+ * (csrc/conv_ws.hip: 3x3, cin = 64, bf16, cout a multiple of 64; with a ReLU-mask / fused 1x1 term
+ * only for cout = 64 and ref == x2), 0 when the general implicit-GEMM kernel takes it.  has_ref: the
+ * launch carries `ref` (STV_MASK) and/or the fused term's x2; has_pool: it emits the pooled map. */
+int stv_conv_uses_ws(int H, int W, int cin, int cout, int taps, int dtype, int flags, int has_ref, int has_pool);
+
 /* MaxPool2d(2,2) forward / backward (first-max-wins like torch); backward
  * optionally applies the ReLU mask of the stored pre-pool activation (STV_MASK) and
  * accumulates (STV_ACCUM).  With STV_POOL_IDX `x` is the [H/2][W/2][C] byte map written by

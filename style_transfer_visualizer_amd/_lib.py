@@ -68,6 +68,7 @@ SIGNATURES = {
     "stv_conv_igemm_dual": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                     c_int, c_int, c_int, c_void_p]),
     "stv_conv_tune": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "stv_conv_uses_ws": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "stv_conv_config": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "stv_maxpool_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "stv_maxpool_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -1,0 +1,24 @@
+// Launch arguments shared by the implicit-GEMM convolution kernels (conv_igemm.hip, conv_ws.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+struct ConvArgs {
+  const void* x;
+  const void* w;
+  const float* bias;
+  const void* ref;
+  void* y;
+  int H, W, cin, cout, flags;
+  void* pool;   // optional second output: MaxPool2d(2,2) of y, [H/2][W/2][cout]
+  void* pool_idx;  // optional third output with it: one byte per pooled element (stv.h: stv_conv_igemm_pool)
+  // optional fused 1x1 term: y = epilogue(mask(ref) * conv3x3(x, w) + x2 . w2^T), x2 [H][W][cin2],
+  // w2 [cout][cin2] plain rows (the Gram backward product riding in the dgrad that shares its output)
+  const void* x2;
+  const void* w2;
+  int cin2;
+};
+
+// conv_ws.hip: weight-stationary persistent kernel for 3x3, Cin = 64, bf16 (the short-K layers).
+// stv_conv_ws_supported() says whether a launch with these arguments can take it.
+bool stv_conv_ws_supported(const ConvArgs& a, int dtype, int taps);
+int stv_conv_ws_launch(const ConvArgs& a, hipStream_t st);

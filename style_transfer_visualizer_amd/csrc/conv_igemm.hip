@@ -38,6 +38,7 @@
 #include <type_traits>
 
 #include "stv_common.h"
+#include "conv_args.h"
 
 #ifdef STV_STAMPS   // diagnostic build only (tools/conv_stamps.cpp): per-workgroup phase time stamps
 __device__ unsigned long long g_stv_stamps[8 * 16384];
@@ -107,22 +108,6 @@ struct Cfg {
   static_assert(TH % WM == 0 && BN % (WN * 32) == 0, "tile split");
   static_assert(BN % 16 == 0, "swizzle period");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-};
-
-struct ConvArgs {
-  const void* x;
-  const void* w;
-  const float* bias;
-  const void* ref;
-  void* y;
-  int H, W, cin, cout, flags;
-  void* pool;   // optional second output: MaxPool2d(2,2) of y, [H/2][W/2][cout]
-  void* pool_idx;  // optional third output with it: one byte per pooled element (stv.h: stv_conv_igemm_pool)
-  // optional fused 1x1 term: y = epilogue(mask(ref) * conv3x3(x, w) + x2 . w2^T), x2 [H][W][cin2],
-  // w2 [cout][cin2] plain rows (the Gram backward product riding in the dgrad that shares its output)
-  const void* x2;
-  const void* w2;
-  int cin2;
 };
 
 template <typename T> struct Frag;
@@ -772,6 +757,8 @@ int launch_mfma(const ConvArgs& a, int cfg, hipStream_t st) {
 
 template <typename T, int TAPS>
 int launch_typed(const ConvArgs& a, hipStream_t st) {
+  // short-K layers (Cin = 64, bf16): weight-stationary persistent kernel (conv_ws.hip)
+  if (stv_conv_ws_supported(a, elem_traits<T>::kDtype, TAPS)) return stv_conv_ws_launch(a, st);
   int cfg = choose_cfg(a.H, a.W, a.cin, a.cout, (int)sizeof(T), TAPS);
   if ((cfg == 7 || cfg == 8) && a.pool != nullptr) cfg = 4;      // a 2-row tile holds one row per wave: no pooling window
   if (cfg < 0) {
@@ -859,6 +846,14 @@ int tune_typed(int H, int W, int cin, int cout, int taps, hipStream_t st) {
 
 extern "C" int stv_conv_config(int H, int W, int cin, int cout, int taps, int dtype) {
   return choose_cfg(H, W, cin, cout, dtype == STV_BF16 ? 2 : 4, taps);
+}
+
+extern "C" int stv_conv_uses_ws(int H, int W, int cin, int cout, int taps, int dtype, int flags, int has_ref, int has_pool) {
+  static const char dummy = 0;
+  ConvArgs a{&dummy, &dummy, nullptr, has_ref ? &dummy : nullptr, const_cast<char*>(&dummy), H, W, cin, cout, flags,
+             has_pool ? const_cast<char*>(&dummy) : nullptr, nullptr, has_ref ? &dummy : nullptr, has_ref ? &dummy : nullptr,
+             has_ref ? 64 : 0};
+  return stv_conv_ws_supported(a, dtype, taps) ? 1 : 0;
 }
 
 extern "C" int stv_conv_tune(int H, int W, int cin, int cout, int taps, int dtype, void* stream) {

@@ -1,0 +1,399 @@
+// Weight-stationary persistent 3x3 convolution for the short-K layers (Cin = 64, bf16), NHWC.
+//
+// The general kernel (conv_igemm.hip) streams K through an LDS ring: with Cin = 64 that is four
+// K-stages per output tile, and a workgroup spends more than a third of its life in the first DMA
+// round trip and the final stores.  Here K is short enough to turn the loop
+// inside out:
+//
+//  * all 9 x 64 x 64 weights of a 64-channel output block stay resident for the whole kernel - in
+//    REGISTERS: a wave owns 32 output channels, i.e. 36 MFMA B-fragments = 144 VGPRs per lane
+//    (four waves per workgroup, one per SIMD, 512 VGPRs each).  Weights never touch LDS, so the
+//    LDS read traffic per MFMA is A fragments only: 18 x 16 B per 36 MFMAs against (12 + 9) per 18
+//    in the general kernel's 8x64 tile, which ran into the 128 B/clk LDS limit;
+//  * workgroups are persistent (one per CU) and walk over 8 x 32 pixel tiles.  The whole-K halo
+//    tile of the NEXT tile (10 x 34 pixels x 128 B = 44 KB, LDS-DMA, zero-filled outside the
+//    image) lands while the current one is multiplied: one barrier per tile, no K-stage barriers,
+//    144 MFMAs back to back per wave;
+//  * the tile's stores are issued after that barrier and drain under the next tile's MFMAs.
+//
+// Forward form: y = [relu](conv3x3([relu]x, w) + bias), optional fused MaxPool2d(2,2) + arg-max map
+// (same epilogue arithmetic as conv_igemm.hip).  Backward form (DG): y = mask(z > 0) * conv3x3(dy, wb)
+// + z . S^T with z the 64-channel pre-activation map that is both the ReLU mask and the Gram tap's
+// features (stv_conv_igemm_dual with ref == x2): its 8 x 32 tile rides in LDS beside the halo tile.
+//
+// Fragment layouts, swizzle and accumulator layout are those of conv_igemm.hip: MFMA rows = output
+// channels, columns = pixels; a lane of an accumulator holds 16 channels (4 groups of 4) of one pixel.
+#include <stdlib.h>
+
+#include <mutex>
+
+#include "stv_common.h"
+#include "conv_args.h"
+
+namespace {
+
+constexpr int TH = 8, TW = 32;                     // workgroup tile: 8 rows x 32 pixels
+constexpr int MT = 4;                              // rows per wave (two waves along M, two along N)
+constexpr int IN_H = TH + 2, IN_W = TW + 2, IN_PIX = IN_H * IN_W;   // 10 x 34 halo tile
+constexpr int KB = 32, CK = 16, NSTAGE = 4;        // Cin = 64 = four K-stages of 16 channels (32 bytes)
+constexpr int IN_PIECES = (IN_PIX * 2 + 63) / 64;  // 1-KiB DMA pieces per stage (64 slots of 16 B)
+constexpr int IN_STAGE = IN_PIECES * 1024;
+constexpr int IN_BYTES = NSTAGE * IN_STAGE;        // 45,056
+constexpr int F_PIX = TH * TW;
+constexpr int F_PIECES = F_PIX * 2 / 64;           // 8
+constexpr int F_STAGE = F_PIECES * 1024;
+constexpr int F_BYTES = NSTAGE * F_STAGE;          // 32,768
+constexpr int AROWS = MT + 2;
+constexpr uint32_t kOob = 0x80000000u;             // >= num_records of every tensor accepted here
+
+template <bool DG> struct WsLds { static constexpr int BUF = IN_BYTES + (DG ? F_BYTES : 0), BYTES = 2 * BUF; };
+static_assert(WsLds<true>::BYTES <= 160 * 1024, "LDS budget");
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ bf16x8v relu_frag(bf16x8v v, uint32_t floor) {
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const s16x8 lo = (s16x8)((short)(floor & 0xFFFFu));
+  return __builtin_bit_cast(bf16x8v, __builtin_elementwise_max(__builtin_bit_cast(s16x8, v), lo));
+}
+
+template <bool DG>
+__global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgroups) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  using lds_ptr = __attribute__((address_space(3))) void*;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 3;     // scalar; also the K-stage this wave fetches
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+
+  // persistent mapping: this workgroup owns one 64-channel output block and every `tstride`-th tile
+  const int tiles_x = (a.W + TW - 1) / TW;
+  const int ntiles = tiles_x * ((a.H + TH - 1) / TH);
+  const int ncb = a.cout / 64;
+  const int cb = (int)blockIdx.x % ncb;
+  const int t_first = (int)blockIdx.x / ncb, tstride = n_workgroups / ncb;
+  const int n0 = cb * 64;
+  const int nb = n0 + wn * 32;                                       // first output channel of this wave
+
+  const bf16_t* __restrict__ xin = static_cast<const bf16_t*>(a.x);
+  const bool w_blocked = (a.flags & STV_W_BLOCKED) != 0;
+  const uint32_t relu_floor = (a.flags & STV_RELU_IN) ? 0u : 0x80008000u;
+  const int x_bytes = a.H * a.W * 64 * 2;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(xin), 0, x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_f = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(DG ? a.ref : nullptr), 0, DG ? a.H * a.W * 64 * 2 : 0, 0x00020000);
+
+  // ---- resident weights: 4 stages x 9 taps, one 16-byte fragment each (row = channel nb + r, k = 8h..8h+7)
+  bf16x8v wreg[NSTAGE][9];
+  {
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, 9 * a.cout * 64 * 2, 0x00020000);
+#pragma unroll
+    for (int s = 0; s < NSTAGE; ++s)
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int n = nb + r;
+        const int elem = w_blocked ? (((tap * NSTAGE + s) * a.cout + n) * CK + h * 8) : ((tap * a.cout + n) * 64 + s * CK + h * 8);
+        wreg[s][tap] = __builtin_bit_cast(bf16x8v, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (uint32_t)(elem * 2), 0, 0));
+      }
+  }
+  bf16x8v sreg[NSTAGE];          // DG with a fused 1x1 term: S rows of this wave's channels (plain [cout][64])
+  const bool dual = DG && a.x2 != nullptr;
+  if (DG) {
+    const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w2), 0, dual ? 64 * 64 * 2 : 0, 0x00020000);
+#pragma unroll
+    for (int s = 0; s < NSTAGE; ++s)
+      sreg[s] = __builtin_bit_cast(bf16x8v, __builtin_amdgcn_raw_buffer_load_b128(rs_s, (uint32_t)((((nb - n0) + r) * 64 + s * CK + h * 8) * 2), 0, 0));
+  }
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, a.bias != nullptr ? a.cout * 4 : 0, 0x00020000);
+  f32x4 bias_v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (uint32_t)((nb + 8 * j + 4 * h) * 4), 0, 0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bias_v[j][e] = __uint_as_float(t[e]);
+  }
+
+  // ---- DMA bookkeeping.  Wave w fetches K-stage w of a tile: IN_PIECES pieces of the halo tile (and
+  // F_PIECES of the centre tile of z).  Slot v = piece * 64 + lane holds half (v & 1) ^ swizzle of pixel
+  // v >> 1; its source offset is tile_base + rel, with rel a per-lane constant of the kernel.
+  int in_rel[IN_PIECES], in_yx[IN_PIECES];
+#pragma unroll
+  for (int p = 0; p < IN_PIECES; ++p) {
+    const int pix = p * 32 + (lane >> 1);
+    const int half = (lane & 1) ^ ((pix >> 3) & 1);
+    const int py = pix / IN_W, px = pix - py * IN_W;
+    in_rel[p] = (py * a.W + px) * 128 + half * 16;
+    in_yx[p] = pix < IN_PIX ? ((py << 8) | px) : (0x3FFF << 8);      // slots past the tile: never in range
+  }
+  const int f_half = (lane & 1) ^ (((lane >> 1) >> 3) & 1);           // pixel = p * 32 + (lane >> 1): bit 3 is the lane's
+
+  auto issue_tile = [&](int t, char* buf) {
+    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int base = ((y0 - 1) * a.W + (x0 - 1)) * 128;
+    char* dst = buf + wave * IN_STAGE;
+#pragma unroll
+    for (int p = 0; p < IN_PIECES; ++p) {
+      const int gy = y0 - 1 + (in_yx[p] >> 8), gx = x0 - 1 + (in_yx[p] & 255);
+      const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+      const uint32_t off = ok ? (uint32_t)(base + in_rel[p]) : kOob;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr)(dst + p * 1024), 16, off, wave * KB, 0, 0);
+    }
+    if (DG) {
+      char* fdst = buf + IN_BYTES + wave * F_STAGE;
+#pragma unroll
+      for (int p = 0; p < F_PIECES; ++p) {
+        const int gy = y0 + p, gx = x0 + (lane >> 1);
+        const bool ok = gy < a.H && gx < a.W;
+        const uint32_t off = ok ? (uint32_t)((gy * a.W + gx) * 128 + f_half * 16) : kOob;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_f, (lds_ptr)(fdst + p * 1024), 16, off, wave * KB, 0, 0);
+      }
+    }
+  };
+
+  // lane-constant LDS offsets of this lane's fragments inside a tile buffer (stage 0)
+  int a_addr[3][AROWS];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+    for (int j = 0; j < AROWS; ++j) {
+      const int pix = (wm * MT + j) * IN_W + dx + r;
+      a_addr[dx][j] = pix * KB + ((h ^ ((pix >> 3) & 1)) << 4);
+    }
+
+  const bool relu_out = (a.flags & STV_RELU_OUT) != 0;
+  const bool do_mask = DG && (a.flags & STV_MASK) != 0;
+  const int out_bytes = a.H * a.W * a.cout * 2;
+  const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, out_bytes, 0x00020000);
+
+  // ---- prologue: first two tiles in flight, weights in registers
+  char* const buf0 = smem;
+  char* const buf1 = smem + WsLds<DG>::BUF;
+  int t = t_first;
+  if (t < ntiles) issue_tile(t, buf0);
+  if (t + tstride < ntiles) issue_tile(t + tstride, buf1);
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+
+  int parity = 0;
+  for (; t < ntiles; t += tstride, parity ^= 1) {
+    char* const cur = parity ? buf1 : buf0;
+    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    const int y0 = ty * TH, x0 = tx * TW;
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mt][i] = 0.0f;
+
+    // ---- 4 stages x 3 columns x 3 rows of taps, A columns fetched one column ahead
+    bf16x8v af[2][AROWS];
+    auto load_col = [&](int col, int set) {          // col = stage * 3 + dx
+      const int s = col / 3, dx = col - s * 3;
+#pragma unroll
+      for (int j = 0; j < AROWS; ++j)
+        af[set][j] = relu_frag(*reinterpret_cast<const bf16x8v*>(cur + s * IN_STAGE + a_addr[dx][j]), relu_floor);
+    };
+    load_col(0, 0);
+#pragma unroll
+    for (int col = 0; col < NSTAGE * 3; ++col) {
+      const int s = col / 3, dx = col - s * 3;
+      if (col + 1 < NSTAGE * 3) load_col(col + 1, (col + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[s][dy * 3 + dx], af[col & 1][mt + dy], acc[mt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    if (DG) {
+      // ReLU mask of the first term (z > 0), read from the z tile in the accumulator layout, then the
+      // 1x1 term z . S^T onto the same accumulators - both before the tile buffer is handed back
+      const char* fb = cur + IN_BYTES;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int fp = (wm * MT + mt) * TW + r;
+        const int swz = (fp >> 3) & 1;
+        if (do_mask) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int off = (2 * wn + (j >> 1)) * F_STAGE + fp * KB + (((j & 1) ^ swz) << 4) + 8 * h;
+            const uint2 m = *reinterpret_cast<const uint2*>(fb + off);
+            acc[mt][4 * j + 0] = ((int)(m.x << 16) > 0) ? acc[mt][4 * j + 0] : 0.0f;
+            acc[mt][4 * j + 1] = ((int)(m.x & 0xFFFF0000u) > 0) ? acc[mt][4 * j + 1] : 0.0f;
+            acc[mt][4 * j + 2] = ((int)(m.y << 16) > 0) ? acc[mt][4 * j + 2] : 0.0f;
+            acc[mt][4 * j + 3] = ((int)(m.y & 0xFFFF0000u) > 0) ? acc[mt][4 * j + 3] : 0.0f;
+          }
+        }
+        if (dual) {
+#pragma unroll
+          for (int s = 0; s < NSTAGE; ++s) {
+            const bf16x8v zf = *reinterpret_cast<const bf16x8v*>(fb + s * F_STAGE + fp * KB + ((h ^ swz) << 4));
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sreg[s], zf, acc[mt], 0, 0, 0);
+          }
+        }
+      }
+    }
+
+    // ---- hand the buffer back: the next tile has landed, the tile after it starts streaming in
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (t + 2 * tstride < ntiles) issue_tile(t + 2 * tstride, cur);
+
+    // ---- epilogue in registers (conv_igemm.hip's, for NT = 1): bias, ReLU, pack, half-wave swap, 16-byte stores
+    auto emit = [&](auto&& val, auto&& pix_off, const __amdgpu_buffer_rsrc_t& rs_out, int MTN) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        if (mt >= MTN) continue;
+        const uint32_t poff = pix_off(mt);
+        uint32_t px[4], py[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = val(mt, 4 * j + e) + bias_v[j][e];
+            if (relu_out) v[e] = fmaxf(v[e], 0.0f);
+          }
+          px[j] = pack_bf16x2(v[0], v[1]);
+          py[j] = pack_bf16x2(v[2], v[3]);
+        }
+#pragma unroll
+        for (int jp = 0; jp < 4; jp += 2) {
+          const auto sx = __builtin_amdgcn_permlane32_swap(px[jp], px[jp + 1], false, false);
+          const auto sy = __builtin_amdgcn_permlane32_swap(py[jp], py[jp + 1], false, false);
+          const u32x4 out = {sx[0], sy[0], sx[1], sy[1]};
+          const int nn = nb + 8 * jp + 8 * h;
+          const uint32_t off = poff != kOob ? poff + (uint32_t)(nn * 2) : kOob;
+          __builtin_amdgcn_raw_buffer_store_b128(out, rs_out, off, 0, 0);
+        }
+      }
+    };
+    auto full_off = [&](int mt) -> uint32_t {
+      const int gy = y0 + wm * MT + mt, gx = x0 + r;
+      return (gy < a.H && gx < a.W) ? (uint32_t)(((gy * a.W + gx) * a.cout) * 2) : kOob;
+    };
+    emit([&](int mt, int i) { return acc[mt][i]; }, full_off, rs_y, MT);
+
+    if (!DG && a.pool != nullptr) {
+      // fused MaxPool2d(2,2) + arg-max byte map: see conv_igemm.hip (same arithmetic, same tie rule)
+      const int Hp = a.H >> 1, Wp = a.W >> 1;
+      const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(a.pool, 0, Hp * Wp * a.cout * 2, 0x00020000);
+      f32x16 pm[MT / 2];
+#pragma unroll
+      for (int mp = 0; mp < MT / 2; ++mp)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float v = fmaxf(acc[2 * mp][i], acc[2 * mp + 1][i]);
+          pm[mp][i] = fmaxf(v, __shfl_xor(v, 1, 64));
+        }
+      auto pool_off = [&](int mp) -> uint32_t {
+        const int gyp = ((y0 + wm * MT) >> 1) + mp, gxp = (x0 + r) >> 1;
+        return ((r & 1) == 0 && gyp < Hp && gxp < Wp) ? (uint32_t)(((gyp * Wp + gxp) * a.cout) * 2) : kOob;
+      };
+      emit([&](int mp, int i) { return pm[mp < MT / 2 ? mp : 0][i]; }, pool_off, rs_p, MT / 2);
+      if (a.pool_idx != nullptr) {
+        const __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc(a.pool_idx, 0, Hp * Wp * a.cout, 0x00020000);
+        auto stored = [&](float v) -> float {
+          if (relu_out) v = fmaxf(v, 0.0f);
+          return bf16_to_f32(f32_to_bf16(v));
+        };
+        auto right = [](float v) -> float {
+          return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+        };
+#pragma unroll
+        for (int mp = 0; mp < MT / 2; ++mp) {
+          const int gyp = ((y0 + wm * MT) >> 1) + mp, gxp = (x0 + r) >> 1;
+          const bool pix_ok = (r & 1) == 0 && gyp < Hp && gxp < Wp;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            uint32_t word = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float tl = stored(acc[2 * mp][4 * j + e] + bias_v[j][e]);
+              const float bl = stored(acc[2 * mp + 1][4 * j + e] + bias_v[j][e]);
+              const float tr = right(tl), br = right(bl);
+              float best = tl;
+              uint32_t code = 0;
+              if (tr > best) { best = tr; code = 1; }
+              if (bl > best) { best = bl; code = 2; }
+              if (br > best) { best = br; code = 3; }
+              if (best > 0.0f) code |= 4;
+              word |= code << (8 * e);
+            }
+            const int nn = nb + 8 * j + 4 * h;
+            const uint32_t off = pix_ok ? (uint32_t)((gyp * Wp + gxp) * a.cout + nn) : kOob;
+            __builtin_amdgcn_raw_buffer_store_b32(word, rs_i, off, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  // every DMA issued was waited for inside the loop (the last two iterations issue none)
+#endif
+}
+
+int device_cus() {
+  static std::mutex mu;
+  static int cus[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  std::lock_guard<std::mutex> lk(mu);
+  if (cus[dev] == 0) {
+    hipDeviceProp_t p;
+    cus[dev] = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+  }
+  return cus[dev];
+}
+
+template <bool DG>
+int launch_ws(const ConvArgs& a, hipStream_t st) {
+  if (stv_set_max_lds(reinterpret_cast<const void*>(&conv_ws_kernel<DG>), WsLds<DG>::BYTES) != STV_OK) return STV_ERR_LAUNCH;
+  const int ntiles = ceil_div(a.W, TW) * ceil_div(a.H, TH);
+  const int ncb = a.cout / 64;
+  int per_cb = device_cus() / ncb;                   // one persistent workgroup per CU
+  if (per_cb < 1) per_cb = 1;
+  if (per_cb > ntiles) per_cb = ntiles;
+  const int n_wg = per_cb * ncb;
+  hipLaunchKernelGGL(conv_ws_kernel<DG>, dim3(n_wg), dim3(256), WsLds<DG>::BYTES, st, a, n_wg);
+  STV_CHECK_LAUNCH();
+  return STV_OK;
+}
+
+}  // namespace
+
+bool stv_conv_ws_supported(const ConvArgs& a, int dtype, int taps) {
+  // A/B knob; forcing a tile configuration of the general kernel (STV_CONV_CFG) also means: use that kernel
+  const char* off = getenv("STV_CONV_WS");
+  const bool enabled = !(off && atoi(off) == 0) && getenv("STV_CONV_CFG") == nullptr;
+  if (!enabled || dtype != STV_BF16 || taps != 9 || a.cin != 64 || a.cout % 64 != 0) return false;
+  if (a.flags & STV_ACCUM) return false;
+  if ((size_t)a.H * a.W * (size_t)(a.cout > 64 ? a.cout : 64) * 2 >= ((size_t)1 << 31)) return false;
+  const bool has_f = (a.flags & STV_MASK) != 0 || a.x2 != nullptr;
+  if (has_f) {
+    // the z tile in LDS is 64 channels wide and serves both as ReLU mask and as the 1x1 term's input
+    if (a.cout != 64 || a.pool != nullptr) return false;
+    if (a.x2 != nullptr && (a.cin2 != 64 || a.w2 == nullptr)) return false;
+    if ((a.flags & STV_MASK) && a.x2 != nullptr && a.ref != a.x2) return false;
+    if (a.flags & (STV_RELU_IN | STV_RELU_OUT)) return false;
+    if (a.bias != nullptr) return false;
+  }
+  return true;
+}
+
+int stv_conv_ws_launch(const ConvArgs& a, hipStream_t st) {
+  const bool has_f = (a.flags & STV_MASK) != 0 || a.x2 != nullptr;
+  if (!has_f) return launch_ws<false>(a, st);
+  ConvArgs b = a;
+  if (b.ref == nullptr) b.ref = b.x2;              // the z tile is fetched through `ref`
+  return launch_ws<true>(b, st);
+}

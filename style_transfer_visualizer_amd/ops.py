@@ -75,6 +75,12 @@ def conv_uses_mfma(H: int, W: int, cin: int, cout: int, dtype: torch.dtype) -> b
     return int(_lib.load().stv_conv_config(H, W, cin, cout, 9, dtype_code(dtype))) >= 0
 
 
+def conv_uses_ws(H: int, W: int, cin: int, cout: int, dtype: torch.dtype, *, flags: int = 0, has_ref: bool = False,
+                 has_pool: bool = False) -> bool:
+    """True when this 3x3 launch runs on the weight-stationary persistent kernel (csrc/conv_ws.hip)."""
+    return bool(_lib.load().stv_conv_uses_ws(H, W, cin, cout, 9, dtype_code(dtype), flags, int(has_ref), int(has_pool)))
+
+
 def conv_tune(H: int, W: int, cin: int, cout: int, taps: int, dtype: torch.dtype) -> int:
     """Measure the tile configurations for one conv shape once (stv_conv_tune); returns the choice (-1: direct kernel)."""
     r = int(_lib.load().stv_conv_tune(H, W, cin, cout, taps, dtype_code(dtype), _stream()))

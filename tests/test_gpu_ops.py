@@ -197,6 +197,78 @@ def test_conv_igemm_with_fused_maxpool(dtype, cfg, case, monkeypatch):
         assert torch.equal(a, b2), f"idx backward differs, flags={flags}"
 
 
+@pytest.mark.parametrize("case", [(64, 75, 101), (128, 40, 72), (64, 8, 32), (64, 13, 7), (64, 512, 512), (128, 256, 320)])
+def test_conv_ws_forward_pool_and_backward(case):
+    """The weight-stationary persistent kernel (csrc/conv_ws.hip; bf16, Cin = 64): forward with bias /
+    ReLU-on-load / ReLU / fused max-pool + arg-max map, and the backward form mask(z>0)*dgrad + z.S^T,
+    on ragged images, on single-tile images and on images with several tiles per workgroup."""
+    cout, H, W = case
+    dtype = torch.bfloat16
+    assert ops.conv_uses_ws(H, W, 64, cout, dtype, flags=ops.RELU_IN | ops.RELU_OUT | ops.W_BLOCKED)
+    x = rnd((1, 64, H, W), 141)
+    w = rnd((cout, 64, 3, 3), 142, -1, 1) * (2.0 / (9 * 64)) ** 0.5
+    b = rnd((cout,), 143, -0.2, 0.2)
+    xq, wq = q(x, dtype), q(w, dtype)
+    for blocked in (True, False):
+        wp = ops.pack_weights_fwd(w).to(dtype).to(DEV)
+        if blocked:
+            wp = ops.block_weights(wp)
+        for flags in (0, ops.RELU_IN | ops.RELU_OUT):
+            ref = F.conv2d(F.relu(xq) if flags & ops.RELU_IN else xq, wq, b, padding=1)
+            ref = F.relu(ref) if flags & ops.RELU_OUT else ref
+            y = ops.conv_igemm(ops.to_nhwc(x, dtype).to(DEV), wp, b.to(DEV), flags=flags)
+            assert_close(ops.from_nhwc(y), ref, dtype, 9 * 64, f"ws fwd {case} flags={flags} blocked={blocked}")
+    # fused pool + arg-max map
+    if H >= 2 and W >= 2:
+        assert ops.conv_uses_ws(H, W, 64, cout, dtype, flags=ops.RELU_OUT | ops.W_BLOCKED, has_pool=True)
+        wp = ops.block_weights(ops.pack_weights_fwd(w).to(dtype).to(DEV))
+        idx = torch.full((H // 2, W // 2, cout), 255, device=DEV, dtype=torch.uint8)
+        y, yp = ops.conv_igemm_pool(ops.to_nhwc(x, dtype).to(DEV), wp, b.to(DEV), flags=ops.RELU_OUT, pool_idx=idx)
+        assert_close(ops.from_nhwc(y), F.relu(F.conv2d(xq, wq, b, padding=1)), dtype, 9 * 64, f"ws conv+pool {case}")
+        assert torch.equal(ops.from_nhwc(yp).cpu(), F.max_pool2d(ops.from_nhwc(y).cpu(), 2, 2))
+        assert int(idx.max()) <= 7
+        dyp = ops.to_nhwc(rnd((1, cout, H // 2, W // 2), 144), dtype).to(DEV)
+        for flags in (0, ops.MASK):
+            a_, b_ = torch.zeros_like(y), torch.zeros_like(y)
+            ops.maxpool_bwd(y, dyp, out=a_, flags=flags)
+            ops.maxpool_bwd_idx(idx, dyp, H, W, out=b_, flags=flags)
+            assert torch.equal(a_, b_), f"ws arg-max map differs from the activation-based routing, flags={flags}"
+    # backward form (64 -> 64 only): mask and / or the fused Gram term
+    if cout == 64:
+        dy = rnd((1, 64, H, W), 145)
+        z = rnd((1, 64, H, W), 146)
+        s_mat = rnd((64, 64), 147, -0.02, 0.02)
+        s_mat = (s_mat + s_mat.t()) * 0.5
+        dyq, zq, sq = q(dy, dtype), q(z, dtype), q(s_mat, dtype)
+        xr = torch.zeros(1, 64, H, W, requires_grad=True)
+        F.conv2d(xr, wq, None, padding=1).backward(dyq)
+        wb = ops.block_weights(ops.pack_weights_bwd(w).to(dtype).to(DEV))
+        zn = ops.to_nhwc(z, dtype).to(DEV)
+        second = torch.einsum("bchw,nc->bnhw", zq, sq)
+        for mask in (False, True):
+            assert ops.conv_uses_ws(H, W, 64, 64, dtype, flags=(ops.MASK if mask else 0) | ops.W_BLOCKED, has_ref=True)
+            first = xr.grad * ((zq > 0).float() if mask else 1.0)
+            out = ops.conv_igemm_dual(ops.to_nhwc(dy, dtype).to(DEV), wb, zn, sq.to(dtype).to(DEV).contiguous(),
+                                      ref=zn if mask else None, flags=ops.MASK if mask else 0)
+            assert_close(ops.from_nhwc(out), first + second, dtype, 9 * 64 + 64, f"ws dual {case} mask={mask}")
+        out = ops.conv_igemm(ops.to_nhwc(dy, dtype).to(DEV), wb, None, ref=zn, flags=ops.MASK)
+        assert_close(ops.from_nhwc(out), xr.grad * (zq > 0).float(), dtype, 9 * 64, f"ws masked dgrad {case}")
+
+
+def test_conv_ws_matches_the_general_kernel_bitwise(monkeypatch):
+    """Same stage / tap accumulation order as conv_igemm.hip: the two kernels must agree bit for bit."""
+    dtype = torch.bfloat16
+    x = ops.to_nhwc(rnd((1, 64, 96, 160), 151), dtype).to(DEV)
+    w = rnd((128, 64, 3, 3), 152, -1, 1) * (2.0 / (9 * 64)) ** 0.5
+    b = rnd((128,), 153, -0.2, 0.2).to(DEV)
+    wp = ops.block_weights(ops.pack_weights_fwd(w).to(dtype).to(DEV))
+    y_ws = ops.conv_igemm(x, wp, b, flags=ops.RELU_IN)
+    monkeypatch.setenv("STV_CONV_WS", "0")
+    assert not ops.conv_uses_ws(96, 160, 64, 128, dtype, flags=ops.RELU_IN | ops.W_BLOCKED)
+    y_gen = ops.conv_igemm(x, wp, b, flags=ops.RELU_IN)
+    assert torch.equal(y_ws, y_gen)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("case", [(128, 128, 21, 70), (64, 64, 9, 33), (48, 136, 12, 40), (512, 128, 8, 8)])
