@@ -46,7 +46,11 @@ constexpr int F_BYTES = NSTAGE * F_STAGE;          // 32,768
 constexpr int AROWS = MT + 2;
 constexpr uint32_t kOob = 0x80000000u;             // >= num_records of every tensor accepted here
 
-template <bool DG> struct WsLds { static constexpr int BUF = IN_BYTES + (DG ? F_BYTES : 0), BYTES = 2 * BUF; };
+// tile buffers in LDS: the backward form (halo tile + z tile) fits two, the forward form three - the halo
+// tile then streams in two tiles ahead of its use
+template <bool DG> struct WsLds {
+  static constexpr int BUF = IN_BYTES + (DG ? F_BYTES : 0), NB = DG ? 2 : 3, BYTES = NB * BUF;
+};
 static_assert(WsLds<true>::BYTES <= 160 * 1024, "LDS budget");
 
 template <int N>
@@ -60,8 +64,8 @@ __device__ __forceinline__ bf16x8v relu_frag(bf16x8v v, uint32_t floor) {
   return __builtin_bit_cast(bf16x8v, __builtin_elementwise_max(__builtin_bit_cast(s16x8, v), lo));
 }
 
-template <bool DG>
-__global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgroups) {
+template <bool DG, bool RELU_IN>
+__global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgroups, int diag) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using lds_ptr = __attribute__((address_space(3))) void*;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -83,7 +87,6 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgrou
 
   const bf16_t* __restrict__ xin = static_cast<const bf16_t*>(a.x);
   const bool w_blocked = (a.flags & STV_W_BLOCKED) != 0;
-  const uint32_t relu_floor = (a.flags & STV_RELU_IN) ? 0u : 0x80008000u;
   const int x_bytes = a.H * a.W * 64 * 2;
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(xin), 0, x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_f = __builtin_amdgcn_make_buffer_rsrc(
@@ -173,45 +176,65 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgrou
   const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, out_bytes, 0x00020000);
 
   // ---- prologue: first two tiles in flight, weights in registers
-  char* const buf0 = smem;
-  char* const buf1 = smem + WsLds<DG>::BUF;
+  constexpr int NB = WsLds<DG>::NB;
   int t = t_first;
-  if (t < ntiles) issue_tile(t, buf0);
-  if (t + tstride < ntiles) issue_tile(t + tstride, buf1);
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+    if (t + b * tstride < ntiles) issue_tile(t + b * tstride, smem + b * WsLds<DG>::BUF);
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
 
-  int parity = 0;
-  for (; t < ntiles; t += tstride, parity ^= 1) {
-    char* const cur = parity ? buf1 : buf0;
+  int slot = 0;
+  for (; t < ntiles; t += tstride, slot = (slot + 1 == NB) ? 0 : slot + 1) {
+    char* const cur = smem + slot * WsLds<DG>::BUF;
     const int ty = t / tiles_x, tx = t - ty * tiles_x;
     const int y0 = ty * TH, x0 = tx * TW;
 
+    // accumulators start at the bias (zero for a backward pass): the epilogue has no add left
     f32x16 acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[mt][i] = 0.0f;
+      for (int i = 0; i < 16; ++i) acc[mt][i] = DG ? 0.0f : bias_v[i >> 2][i & 3];
 
-    // ---- 4 stages x 3 columns x 3 rows of taps, A columns fetched one column ahead
-    bf16x8v af[2][AROWS];
+    // ---- 4 stages x 3 columns x 3 rows of taps.  One wave per SIMD: nothing else hides an LDS round
+    // trip, so the A fragments of a column are requested TWO columns ahead and (forward pass behind a
+    // ReLU) clamped one column ahead, in the shadow of the 12 MFMAs in between.
+    bf16x8v af[3][AROWS];
     auto load_col = [&](int col, int set) {          // col = stage * 3 + dx
       const int s = col / 3, dx = col - s * 3;
 #pragma unroll
       for (int j = 0; j < AROWS; ++j)
-        af[set][j] = relu_frag(*reinterpret_cast<const bf16x8v*>(cur + s * IN_STAGE + a_addr[dx][j]), relu_floor);
+        af[set][j] = *reinterpret_cast<const bf16x8v*>(cur + s * IN_STAGE + a_addr[dx][j]);
+    };
+    auto relu_col = [&](int set) {
+      if (RELU_IN) {
+#pragma unroll
+        for (int j = 0; j < AROWS; ++j) af[set][j] = relu_frag(af[set][j], 0u);
+      }
     };
     load_col(0, 0);
+    load_col(1, 1);
+    relu_col(0);
+    if (!(diag & 4))
 #pragma unroll
     for (int col = 0; col < NSTAGE * 3; ++col) {
       const int s = col / 3, dx = col - s * 3;
-      if (col + 1 < NSTAGE * 3) load_col(col + 1, (col + 1) & 1);
+      if (col + 2 < NSTAGE * 3) load_col(col + 2, (col + 2) % 3);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
-          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[s][dy * 3 + dx], af[col & 1][mt + dy], acc[mt], 0, 0, 0);
+          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[s][dy * 3 + dx], af[col % 3][mt + dy], acc[mt], 0, 0, 0);
+      if (col + 1 < NSTAGE * 3) relu_col((col + 1) % 3);
+      if (RELU_IN) {                                   // 12 MFMAs, 24 packed max: two in the shadow of each
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
 
@@ -242,101 +265,114 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgrou
           }
         }
       }
+      // the mask of row mt + 1 (48 VALU) in the shadow of the four 1x1 MFMAs of row mt
+#pragma unroll
+      for (int k = 0; k < 4 * MT; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
+      }
     }
 
-    // ---- hand the buffer back: the next tile has landed, the tile after it starts streaming in
-    wait_vmcnt<0>();
+    // ---- hand the buffer back: the next tile has landed, a later one starts streaming into this buffer.
+    // Two buffers: everything this wave has in flight is drained (the DMA of the next tile and the
+    // previous tile's stores were both issued a whole tile ago).  Three buffers: the DMA issued last
+    // (two tiles ahead) may stay in flight - loads retire in order, so "at most that DMA's pieces
+    // outstanding" implies the next tile has landed; stores are issued BEFORE the DMA of an iteration so
+    // that they can only make this counted wait longer, never satisfied early.
+    const bool more = t + NB * tstride < ntiles && !(diag & 2);
+    if (NB == 3 && t + 2 * tstride < ntiles && !(diag & 2)) wait_vmcnt<IN_PIECES>();
+    else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    if (t + 2 * tstride < ntiles) issue_tile(t + 2 * tstride, cur);
+    if (NB == 2 && more) issue_tile(t + NB * tstride, cur);
 
-    // ---- epilogue in registers (conv_igemm.hip's, for NT = 1): bias, ReLU, pack, half-wave swap, 16-byte stores
-    auto emit = [&](auto&& val, auto&& pix_off, const __amdgpu_buffer_rsrc_t& rs_out, int MTN) {
+    // ---- epilogue in registers: round + ReLU on packed words, half-wave swap, 16-byte stores.
+    // (The bias already sits in the accumulators.)  P[mt][0..3] = channel pairs (0,1) of groups j,
+    // P[mt][4..7] = pairs (2,3): a lane holds channels nb + 8j + 4h + e of pixel (row mt, column r).
+    typedef __attribute__((ext_vector_type(2))) short s16x2;
+    const s16x2 relu_lo = (s16x2)((short)(relu_out ? 0 : -32768));
+    uint32_t P[MT][8];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        if (mt >= MTN) continue;
-        const uint32_t poff = pix_off(mt);
-        uint32_t px[4], py[4];
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float v[4];
+      for (int j = 0; j < 4; ++j) {
+        // ReLU after the rounding, on the packed words (a negative bf16 is a negative int16): same result
+        P[mt][j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(
+            __builtin_bit_cast(s16x2, pack_bf16x2(acc[mt][4 * j + 0], acc[mt][4 * j + 1])), relu_lo));
+        P[mt][4 + j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(
+            __builtin_bit_cast(s16x2, pack_bf16x2(acc[mt][4 * j + 2], acc[mt][4 * j + 3])), relu_lo));
+      }
+    auto store_rows = [&](const uint32_t (&Q)[8], uint32_t poff, const __amdgpu_buffer_rsrc_t& rs_out) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[e] = val(mt, 4 * j + e) + bias_v[j][e];
-            if (relu_out) v[e] = fmaxf(v[e], 0.0f);
-          }
-          px[j] = pack_bf16x2(v[0], v[1]);
-          py[j] = pack_bf16x2(v[2], v[3]);
-        }
-#pragma unroll
-        for (int jp = 0; jp < 4; jp += 2) {
-          const auto sx = __builtin_amdgcn_permlane32_swap(px[jp], px[jp + 1], false, false);
-          const auto sy = __builtin_amdgcn_permlane32_swap(py[jp], py[jp + 1], false, false);
-          const u32x4 out = {sx[0], sy[0], sx[1], sy[1]};
-          const int nn = nb + 8 * jp + 8 * h;
-          const uint32_t off = poff != kOob ? poff + (uint32_t)(nn * 2) : kOob;
-          __builtin_amdgcn_raw_buffer_store_b128(out, rs_out, off, 0, 0);
-        }
+      for (int jp = 0; jp < 4; jp += 2) {
+        // lanes 32-63 of the group-jp register <-> lanes 0-31 of the group-(jp+1) register
+        const auto sx = __builtin_amdgcn_permlane32_swap(Q[jp], Q[jp + 1], false, false);
+        const auto sy = __builtin_amdgcn_permlane32_swap(Q[4 + jp], Q[4 + jp + 1], false, false);
+        const u32x4 out = {sx[0], sy[0], sx[1], sy[1]};
+        const int nn = nb + 8 * jp + 8 * h;
+        const uint32_t off = (poff != kOob && !(diag & 1)) ? poff + (uint32_t)(nn * 2) : kOob;
+        __builtin_amdgcn_raw_buffer_store_b128(out, rs_out, off, 0, 0);
       }
     };
-    auto full_off = [&](int mt) -> uint32_t {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
       const int gy = y0 + wm * MT + mt, gx = x0 + r;
-      return (gy < a.H && gx < a.W) ? (uint32_t)(((gy * a.W + gx) * a.cout) * 2) : kOob;
-    };
-    emit([&](int mt, int i) { return acc[mt][i]; }, full_off, rs_y, MT);
+      store_rows(P[mt], (gy < a.H && gx < a.W) ? (uint32_t)(((gy * a.W + gx) * a.cout) * 2) : kOob, rs_y);
+    }
 
     if (!DG && a.pool != nullptr) {
-      // fused MaxPool2d(2,2) + arg-max byte map: see conv_igemm.hip (same arithmetic, same tie rule)
+      // Fused MaxPool2d(2,2) + arg-max byte map (stv.h: stv_conv_igemm_pool), on the STORED values: the
+      // packed bf16 words above.  They are >= 0 here (the pool only rides behind a ReLU), so a bf16
+      // compares like its 15-bit integer pattern and `b > a` is the sign of the packed difference
+      // a - b: two channels per instruction, no unpacking.  Window scan order (torch's first-maximum
+      // rule): top-left, top-right, bottom-left, bottom-right; the right column is the neighbouring lane.
       const int Hp = a.H >> 1, Wp = a.W >> 1;
       const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(a.pool, 0, Hp * Wp * a.cout * 2, 0x00020000);
-      f32x16 pm[MT / 2];
-#pragma unroll
-      for (int mp = 0; mp < MT / 2; ++mp)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const float v = fmaxf(acc[2 * mp][i], acc[2 * mp + 1][i]);
-          pm[mp][i] = fmaxf(v, __shfl_xor(v, 1, 64));
-        }
-      auto pool_off = [&](int mp) -> uint32_t {
-        const int gyp = ((y0 + wm * MT) >> 1) + mp, gxp = (x0 + r) >> 1;
-        return ((r & 1) == 0 && gyp < Hp && gxp < Wp) ? (uint32_t)(((gyp * Wp + gxp) * a.cout) * 2) : kOob;
+      const __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc(
+          a.pool_idx, 0, a.pool_idx != nullptr ? Hp * Wp * a.cout : 0, 0x00020000);
+      auto right = [](uint32_t v) -> uint32_t {      // the neighbouring lane's word (quad_perm [1,0,3,2])
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);
       };
-      emit([&](int mp, int i) { return pm[mp < MT / 2 ? mp : 0][i]; }, pool_off, rs_p, MT / 2);
-      if (a.pool_idx != nullptr) {
-        const __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc(a.pool_idx, 0, Hp * Wp * a.cout, 0x00020000);
-        auto stored = [&](float v) -> float {
-          if (relu_out) v = fmaxf(v, 0.0f);
-          return bf16_to_f32(f32_to_bf16(v));
-        };
-        auto right = [](float v) -> float {
-          return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
-        };
+      auto gt = [](uint32_t best, uint32_t cand) -> uint32_t {    // bit 15 of each half: cand > best
+        return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, best) - __builtin_bit_cast(s16x2, cand)) & 0x80008000u;
+      };
+      auto mx = [](uint32_t x, uint32_t y) -> uint32_t {
+        return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, x), __builtin_bit_cast(s16x2, y)));
+      };
 #pragma unroll
-        for (int mp = 0; mp < MT / 2; ++mp) {
-          const int gyp = ((y0 + wm * MT) >> 1) + mp, gxp = (x0 + r) >> 1;
-          const bool pix_ok = (r & 1) == 0 && gyp < Hp && gxp < Wp;
+      for (int mp = 0; mp < MT / 2; ++mp) {
+        const int gyp = ((y0 + wm * MT) >> 1) + mp, gxp = (x0 + r) >> 1;
+        const bool pix_ok = (r & 1) == 0 && gyp < Hp && gxp < Wp;
+        uint32_t Q[8], code[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const uint32_t tl = P[2 * mp][q], bl = P[2 * mp + 1][q];
+          const uint32_t tr = right(tl), br = right(bl);
+          const uint32_t c1 = gt(tl, tr), m1 = mx(tl, tr);
+          const uint32_t c2 = gt(m1, bl), m2 = mx(m1, bl);
+          const uint32_t c3 = gt(m2, br), m3 = mx(m2, br);
+          Q[q] = m3;
+          // position of the first maximum: c3 ? 3 : c2 ? 2 : c1 ? 1 : 0  ->  bit1 = c2 | c3, bit0 = c3 | (c1 & ~c2)
+          const uint32_t b1 = c2 | c3;
+          const uint32_t b0 = (c2 & c3) | (~c2 & (c1 | c3));
+          // bit 2: the winner is positive (!= 0): adding 0x7FFF carries into bit 15 of a non-zero half
+          typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
+          const uint32_t pos = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, m3) + (u16x2)((unsigned short)0x7FFF)) & 0x80008000u;
+          code[q] = (b0 >> 15) | (b1 >> 14) | (pos >> 13);          // per half: a 3-bit code in bits 0-2 / 16-18
+        }
+        store_rows(Q, pix_ok ? (uint32_t)(((gyp * Wp + gxp) * a.cout) * 2) : kOob, rs_p);
+        if (a.pool_idx != nullptr) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            uint32_t word = 0;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float tl = stored(acc[2 * mp][4 * j + e] + bias_v[j][e]);
-              const float bl = stored(acc[2 * mp + 1][4 * j + e] + bias_v[j][e]);
-              const float tr = right(tl), br = right(bl);
-              float best = tl;
-              uint32_t code = 0;
-              if (tr > best) { best = tr; code = 1; }
-              if (bl > best) { best = bl; code = 2; }
-              if (br > best) { best = br; code = 3; }
-              if (best > 0.0f) code |= 4;
-              word |= code << (8 * e);
-            }
+            // channels e = 0,1 come from code[j] (bytes 0 and 2), e = 2,3 from code[4 + j]
+            const uint32_t word = __builtin_amdgcn_perm(code[4 + j], code[j], 0x06040200u);
             const int nn = nb + 8 * j + 4 * h;
-            const uint32_t off = pix_ok ? (uint32_t)((gyp * Wp + gxp) * a.cout + nn) : kOob;
+            const uint32_t off = (pix_ok && !(diag & 1)) ? (uint32_t)((gyp * Wp + gxp) * a.cout + nn) : kOob;
             __builtin_amdgcn_raw_buffer_store_b32(word, rs_i, off, 0, 0);
           }
         }
       }
     }
+    if (NB == 3 && more) issue_tile(t + NB * tstride, cur);
   }
   // every DMA issued was waited for inside the loop (the last two iterations issue none)
 #endif
@@ -355,16 +391,17 @@ int device_cus() {
   return cus[dev];
 }
 
-template <bool DG>
+template <bool DG, bool RELU_IN>
 int launch_ws(const ConvArgs& a, hipStream_t st) {
-  if (stv_set_max_lds(reinterpret_cast<const void*>(&conv_ws_kernel<DG>), WsLds<DG>::BYTES) != STV_OK) return STV_ERR_LAUNCH;
+  if (stv_set_max_lds(reinterpret_cast<const void*>(&conv_ws_kernel<DG, RELU_IN>), WsLds<DG>::BYTES) != STV_OK) return STV_ERR_LAUNCH;
   const int ntiles = ceil_div(a.W, TW) * ceil_div(a.H, TH);
   const int ncb = a.cout / 64;
   int per_cb = device_cus() / ncb;                   // one persistent workgroup per CU
   if (per_cb < 1) per_cb = 1;
   if (per_cb > ntiles) per_cb = ntiles;
   const int n_wg = per_cb * ncb;
-  hipLaunchKernelGGL(conv_ws_kernel<DG>, dim3(n_wg), dim3(256), WsLds<DG>::BYTES, st, a, n_wg);
+  const char* dg = getenv("STV_WS_DIAG");            // timing experiments only (results are then wrong)
+  hipLaunchKernelGGL((conv_ws_kernel<DG, RELU_IN>), dim3(n_wg), dim3(256), WsLds<DG>::BYTES, st, a, n_wg, dg ? atoi(dg) : 0);
   STV_CHECK_LAUNCH();
   return STV_OK;
 }
@@ -373,11 +410,16 @@ int launch_ws(const ConvArgs& a, hipStream_t st) {
 
 bool stv_conv_ws_supported(const ConvArgs& a, int dtype, int taps) {
   // A/B knob; forcing a tile configuration of the general kernel (STV_CONV_CFG) also means: use that kernel
-  const char* off = getenv("STV_CONV_WS");
-  const bool enabled = !(off && atoi(off) == 0) && getenv("STV_CONV_CFG") == nullptr;
-  if (!enabled || dtype != STV_BF16 || taps != 9 || a.cin != 64 || a.cout % 64 != 0) return false;
+  // STV_CONV_WS: 0 = never, 2 = every supported shape, default (1) = where it measured faster than the
+  // general kernel: the 64 -> 64 layers (conv1_2 forward with its pooling epilogue, and its backward)
+  const char* knob = getenv("STV_CONV_WS");
+  const int mode = knob ? atoi(knob) : 1;
+  if (mode == 0 || getenv("STV_CONV_CFG") != nullptr) return false;
+  if (dtype != STV_BF16 || taps != 9 || a.cin != 64 || a.cout % 64 != 0) return false;
+  if (mode == 1 && a.cout != 64) return false;
   if (a.flags & STV_ACCUM) return false;
   if ((size_t)a.H * a.W * (size_t)(a.cout > 64 ? a.cout : 64) * 2 >= ((size_t)1 << 31)) return false;
+  if (a.pool != nullptr && !(a.flags & STV_RELU_OUT)) return false;     // the packed pooling epilogue compares non-negative words
   const bool has_f = (a.flags & STV_MASK) != 0 || a.x2 != nullptr;
   if (has_f) {
     // the z tile in LDS is 64 channels wide and serves both as ReLU mask and as the 1x1 term's input
@@ -392,8 +434,8 @@ bool stv_conv_ws_supported(const ConvArgs& a, int dtype, int taps) {
 
 int stv_conv_ws_launch(const ConvArgs& a, hipStream_t st) {
   const bool has_f = (a.flags & STV_MASK) != 0 || a.x2 != nullptr;
-  if (!has_f) return launch_ws<false>(a, st);
+  if (!has_f) return (a.flags & STV_RELU_IN) ? launch_ws<false, true>(a, st) : launch_ws<false, false>(a, st);
   ConvArgs b = a;
   if (b.ref == nullptr) b.ref = b.x2;              // the z tile is fetched through `ref`
-  return launch_ws<true>(b, st);
+  return launch_ws<true, false>(b, st);
 }

@@ -255,8 +255,9 @@ def test_conv_ws_forward_pool_and_backward(case):
         assert_close(ops.from_nhwc(out), xr.grad * (zq > 0).float(), dtype, 9 * 64, f"ws masked dgrad {case}")
 
 
-def test_conv_ws_matches_the_general_kernel_bitwise(monkeypatch):
-    """Same stage / tap accumulation order as conv_igemm.hip: the two kernels must agree bit for bit."""
+def test_conv_ws_matches_the_general_kernel(monkeypatch):
+    """Same stage / tap accumulation order as conv_igemm.hip; only the bias enters first instead of last
+    (it initialises the accumulators): the two kernels agree except for rare one-ulp roundings."""
     dtype = torch.bfloat16
     x = ops.to_nhwc(rnd((1, 64, 96, 160), 151), dtype).to(DEV)
     w = rnd((128, 64, 3, 3), 152, -1, 1) * (2.0 / (9 * 64)) ** 0.5
@@ -266,7 +267,15 @@ def test_conv_ws_matches_the_general_kernel_bitwise(monkeypatch):
     monkeypatch.setenv("STV_CONV_WS", "0")
     assert not ops.conv_uses_ws(96, 160, 64, 128, dtype, flags=ops.RELU_IN | ops.W_BLOCKED)
     y_gen = ops.conv_igemm(x, wp, b, flags=ops.RELU_IN)
-    assert torch.equal(y_ws, y_gen)
+    a_, g_ = y_ws.float(), y_gen.float()
+    diff = (a_ - g_).abs()
+    assert float((diff > 0).float().mean()) < 2e-3
+    assert float((diff / (2.0 ** -7 * torch.maximum(a_.abs(), g_.abs()) + 1e-6)).max()) <= 1.0
+    # without a bias the accumulation is the same sequence of MFMAs: bit for bit
+    monkeypatch.delenv("STV_CONV_WS")
+    y_ws0 = ops.conv_igemm(x, wp, None, flags=ops.RELU_IN)
+    monkeypatch.setenv("STV_CONV_WS", "0")
+    assert torch.equal(y_ws0, ops.conv_igemm(x, wp, None, flags=ops.RELU_IN))
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
