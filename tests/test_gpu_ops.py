@@ -198,12 +198,13 @@ def test_conv_igemm_with_fused_maxpool(dtype, cfg, case, monkeypatch):
 
 
 @pytest.mark.parametrize("case", [(64, 75, 101), (128, 40, 72), (64, 8, 32), (64, 13, 7), (64, 512, 512), (128, 256, 320)])
-def test_conv_ws_forward_pool_and_backward(case):
+def test_conv_ws_forward_pool_and_backward(case, monkeypatch):
     """The weight-stationary persistent kernel (csrc/conv_ws.hip; bf16, Cin = 64): forward with bias /
     ReLU-on-load / ReLU / fused max-pool + arg-max map, and the backward form mask(z>0)*dgrad + z.S^T,
     on ragged images, on single-tile images and on images with several tiles per workgroup."""
     cout, H, W = case
     dtype = torch.bfloat16
+    monkeypatch.setenv("STV_CONV_WS", "2")          # every supported shape, also those the default leaves to the general kernel
     assert ops.conv_uses_ws(H, W, 64, cout, dtype, flags=ops.RELU_IN | ops.RELU_OUT | ops.W_BLOCKED)
     x = rnd((1, 64, H, W), 141)
     w = rnd((cout, 64, 3, 3), 142, -1, 1) * (2.0 / (9 * 64)) ** 0.5
