@@ -264,6 +264,8 @@ def test_conv_ws_matches_the_general_kernel(monkeypatch):
     w = rnd((128, 64, 3, 3), 152, -1, 1) * (2.0 / (9 * 64)) ** 0.5
     b = rnd((128,), 153, -0.2, 0.2).to(DEV)
     wp = ops.block_weights(ops.pack_weights_fwd(w).to(dtype).to(DEV))
+    monkeypatch.setenv("STV_CONV_WS", "2")
+    assert ops.conv_uses_ws(96, 160, 64, 128, dtype, flags=ops.RELU_IN | ops.W_BLOCKED)
     y_ws = ops.conv_igemm(x, wp, b, flags=ops.RELU_IN)
     monkeypatch.setenv("STV_CONV_WS", "0")
     assert not ops.conv_uses_ws(96, 160, 64, 128, dtype, flags=ops.RELU_IN | ops.W_BLOCKED)
@@ -273,7 +275,7 @@ def test_conv_ws_matches_the_general_kernel(monkeypatch):
     assert float((diff > 0).float().mean()) < 2e-3
     assert float((diff / (2.0 ** -7 * torch.maximum(a_.abs(), g_.abs()) + 1e-6)).max()) <= 1.0
     # without a bias the accumulation is the same sequence of MFMAs: bit for bit
-    monkeypatch.delenv("STV_CONV_WS")
+    monkeypatch.setenv("STV_CONV_WS", "2")
     y_ws0 = ops.conv_igemm(x, wp, None, flags=ops.RELU_IN)
     monkeypatch.setenv("STV_CONV_WS", "0")
     assert torch.equal(y_ws0, ops.conv_igemm(x, wp, None, flags=ops.RELU_IN))
