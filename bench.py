@@ -261,7 +261,6 @@ def run_spatial(args, rank: int, world: int, device: torch.device) -> dict:
     style = synthetic.synthetic_image(1, 1024, 1024).to(device)
     model = core_model.StyleContentModel(S, C, precision=args.precision).to(device)
     targets = model._engine_for(style).capture_style(style)
-    shard = spatial.SpatialShard(model._layers(), S, C, content, targets, dtype=dtype, style_w=1e5, content_w=1.0)
     torch.manual_seed(0)
     x = torch.randn(1, 3, H, W, generator=torch.Generator().manual_seed(0)).to(device)
 
@@ -271,18 +270,28 @@ def run_spatial(args, rank: int, world: int, device: torch.device) -> dict:
             dist.barrier()
         torch.cuda.synchronize(device)
         return time.perf_counter()
+    if args.spatial_mode == "recompute":
+        shard = spatial.SpatialShard(model._layers(), S, C, content, targets, dtype=dtype, style_w=1e5, content_w=1.0)
+        step = lambda: shard.adam_step(x, lr=1e-3)                       # noqa: E731
+        mode = "recomputed 160-row halos"
+        rows = [shard.c0, shard.c1, shard.e0, shard.e1]
+    else:
+        shard = spatial.HaloShard(model._layers(), S, C, content, targets, dtype=dtype, style_w=1e5, content_w=1.0)
+        shard.set_image(x)
+        step = lambda: shard.step("adam", lr=1e-3)                        # noqa: E731
+        mode = f"1-row halo exchange before every 3x3 conv ({shard.exchanges_per_closure} per closure)"
+        rows = [shard.c0, shard.c1]
     for _ in range(args.warmup):
-        x = shard.adam_step(x, lr=1e-3)
+        step()
     t0 = fence()
     for _ in range(args.steps):
-        x = shard.adam_step(x, lr=1e-3)
+        step()
     elapsed = fence() - t0
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    return {"elapsed": elapsed, "rows": [shard.c0, shard.c1, shard.e0, shard.e1],
-            "scores": [float(v) for v in shard.last_scores.cpu()]}
+    return {"elapsed": elapsed, "rows": rows, "mode": mode, "scores": [float(v) for v in shard.last_scores.cpu()]}
 
 
 def cpu_baseline(size: int, threads: int) -> dict:
@@ -349,6 +358,8 @@ def main() -> None:
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only to rehearse N>1 on a single GPU")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--spatial-mode", choices=["exchange", "recompute"], default="exchange",
+                    help="--spatial partition: per-layer 1-row halo exchange (default) or recomputed 160-row halos")
     ap.add_argument("--spatial", action="store_true",
                     help="BASELINE configs[4] instead: one 3840x2160 image, Adam, row strips over the N GPUs")
     args = ap.parse_args()

@@ -239,6 +239,15 @@ size_t stv_lbfgsc_workspace_bytes(size_t n, int history);
 int stv_lbfgsc_step(float* x, const float* grad, void* state, void* workspace, size_t n,
                     int history, int m_max, float lr, float tol_grad, float tol_change,
                     void* stream);
+/* The same step in two halves, for an image sharded over several processes (one 4K image as row strips,
+ * DESIGN.md §6): stv_lbfgsc_dots leaves the step's inner products - partial sums over THIS shard - as
+ * doubles in the workspace at stv_lbfgsc_dots_offset(); the caller all-reduces them (SUM, except entry
+ * *max_index = max|g|: MAX) and stv_lbfgsc_apply then runs the identical scalar recursion on every shard
+ * and updates its own elements.  stv_lbfgsc_step == dots + apply. */
+int stv_lbfgsc_dots(const float* grad, void* state, void* workspace, size_t n, int history, int m_max, void* stream);
+int stv_lbfgsc_apply(float* x, const float* grad, void* state, void* workspace, size_t n, int history, float lr,
+                     float tol_grad, float tol_change, void* stream);
+size_t stv_lbfgsc_dots_offset(size_t n, int history, int* count, int* max_index);
 /* scalars are computed in double on the host exactly as torch does
  * (1-beta1, 1-beta2, 1-beta1**t, sqrt(1-beta2**t)) and passed rounded to fp32 */
 int stv_adam_step(float* x, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,

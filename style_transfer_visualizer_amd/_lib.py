@@ -87,6 +87,9 @@ SIGNATURES = {
     "stv_lbfgsc_state_bytes": (c_size_t, [c_int]),
     "stv_lbfgsc_workspace_bytes": (c_size_t, [c_size_t, c_int]),
     "stv_lbfgsc_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_float, c_float, c_float, c_void_p]),
+    "stv_lbfgsc_dots": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
+    "stv_lbfgsc_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_float, c_float, c_float, c_void_p]),
+    "stv_lbfgsc_dots_offset": (c_size_t, [c_size_t, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "stv_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float, c_float, c_float, c_float, c_float, c_void_p]),
     "stv_program_create": (c_int, [ctypes.POINTER(StvOp), c_int, ctypes.POINTER(c_void_p)]),
     "stv_program_run": (c_int, [c_void_p, c_int, c_void_p]),

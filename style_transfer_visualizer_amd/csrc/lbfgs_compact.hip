@@ -576,38 +576,80 @@ extern "C" size_t stv_lbfgsc_workspace_bytes(size_t n, int history) {
   return floats * sizeof(float);
 }
 
-extern "C" int stv_lbfgsc_step(float* x, const float* grad, void* state, void* workspace, size_t n, int history,
-                               int m_max, float lr, float tol_grad, float tol_change, void* stream) {
-  if (!x || !grad || !state || !workspace || n == 0) return STV_ERR_ARG;
+namespace {
+struct StepGeom { size_t nn; int tile, ntiles, nparts; CWs w; };
+inline StepGeom step_geom(void* workspace, size_t n, int history) {
+  StepGeom g;
+  g.nn = align_up(n, 4096);
+  g.tile = tile_floats(n);
+  g.ntiles = (int)(g.nn / g.tile);
+  g.nparts = g.ntiles * 4;
+  g.w = carve(workspace, n, history, g.nparts);
+  return g;
+}
+}  // namespace
+
+// First half of a step: sweep A + the fixed-order reduction.  Leaves every inner product of the step
+// (5 per history pair + NSCAL scalars) as doubles in the workspace, at stv_lbfgsc_dots_offset().
+extern "C" int stv_lbfgsc_dots(const float* grad, void* state, void* workspace, size_t n, int history, int m_max,
+                               void* stream) {
+  if (!grad || !state || !workspace || n == 0) return STV_ERR_ARG;
   if (history < 1 || history > MAX_HIST) return STV_ERR_ARG;
   if (m_max < 0) m_max = 0;
   if (m_max > history) m_max = history;
   hipStream_t st = static_cast<hipStream_t>(stream);
   CState* s = static_cast<CState*>(state);
-  const size_t nn = align_up(n, 4096);
-  const int tile = tile_floats(n);
-  const int ntiles = (int)(nn / tile);
-  const int nparts = ntiles * 4;
-  const CWs w = carve(workspace, n, history, nparts);
+  const StepGeom g = step_geom(workspace, n, history);
+  if (g.tile == 4096)
+    hipLaunchKernelGGL(pass_a_kernel<4>, dim3(g.ntiles), dim3(256), 0, st, grad, s, g.w, n, g.nn, history, g.nparts);
+  else if (g.tile == 2048)
+    hipLaunchKernelGGL(pass_a_kernel<2>, dim3(g.ntiles), dim3(256), 0, st, grad, s, g.w, n, g.nn, history, g.nparts);
+  else
+    hipLaunchKernelGGL(pass_a_kernel<1>, dim3(g.ntiles), dim3(256), 0, st, grad, s, g.w, n, g.nn, history, g.nparts);
+  hipLaunchKernelGGL(reduce_kernel, dim3(5 * m_max + NSCAL), dim3(256), 0, st, s, g.w, history, g.nparts);
+  STV_CHECK_LAUNCH();
+  return STV_OK;
+}
+
+// Second half: torch's control flow + the recursion on coefficients (from the inner products), then
+// sweep B: d, x += t*d, prev_g = g.
+extern "C" int stv_lbfgsc_apply(float* x, const float* grad, void* state, void* workspace, size_t n, int history,
+                                float lr, float tol_grad, float tol_change, void* stream) {
+  if (!x || !grad || !state || !workspace || n == 0) return STV_ERR_ARG;
+  if (history < 1 || history > MAX_HIST) return STV_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  CState* s = static_cast<CState*>(state);
+  const StepGeom g = step_geom(workspace, n, history);
   const size_t lds = 2 * (size_t)history * (size_t)(history | 1) * sizeof(float);
   if (stv_set_max_lds(reinterpret_cast<const void*>(&solve_kernel), 2 * MAX_HIST * (MAX_HIST | 1) * (int)sizeof(float)) != STV_OK)
     return STV_ERR_LAUNCH;
-  if (tile == 4096)
-    hipLaunchKernelGGL(pass_a_kernel<4>, dim3(ntiles), dim3(256), 0, st, grad, s, w, n, nn, history, nparts);
-  else if (tile == 2048)
-    hipLaunchKernelGGL(pass_a_kernel<2>, dim3(ntiles), dim3(256), 0, st, grad, s, w, n, nn, history, nparts);
+  hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(256), lds, st, s, g.w, history, lr, tol_grad, tol_change);
+  if (g.tile == 4096)
+    hipLaunchKernelGGL(pass_b_kernel<4>, dim3(g.ntiles), dim3(256), 0, st, x, grad, s, g.w, n, g.nn, history);
+  else if (g.tile == 2048)
+    hipLaunchKernelGGL(pass_b_kernel<2>, dim3(g.ntiles), dim3(256), 0, st, x, grad, s, g.w, n, g.nn, history);
   else
-    hipLaunchKernelGGL(pass_a_kernel<1>, dim3(ntiles), dim3(256), 0, st, grad, s, w, n, nn, history, nparts);
-  hipLaunchKernelGGL(reduce_kernel, dim3(5 * m_max + NSCAL), dim3(256), 0, st, s, w, history, nparts);
-  hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(256), lds, st, s, w, history, lr, tol_grad, tol_change);
-  if (tile == 4096)
-    hipLaunchKernelGGL(pass_b_kernel<4>, dim3(ntiles), dim3(256), 0, st, x, grad, s, w, n, nn, history);
-  else if (tile == 2048)
-    hipLaunchKernelGGL(pass_b_kernel<2>, dim3(ntiles), dim3(256), 0, st, x, grad, s, w, n, nn, history);
-  else
-    hipLaunchKernelGGL(pass_b_kernel<1>, dim3(ntiles), dim3(256), 0, st, x, grad, s, w, n, nn, history);
+    hipLaunchKernelGGL(pass_b_kernel<1>, dim3(g.ntiles), dim3(256), 0, st, x, grad, s, g.w, n, g.nn, history);
   STV_CHECK_LAUNCH();
   return STV_OK;
+}
+
+// Where the inner products live: byte offset into the workspace of `count` doubles; entry `max_index`
+// is max|g| (combine across shards with MAX), every other entry is a sum (combine with SUM).
+extern "C" size_t stv_lbfgsc_dots_offset(size_t n, int history, int* count, int* max_index) {
+  const size_t nn = align_up(n, 4096);
+  const int S = history + 1;
+  if (count) *count = 5 * MAX_HIST + NSCAL;
+  if (max_index) *max_index = 5 * MAX_HIST;
+  return (nn * (2 + 2 * (size_t)S) + 2 * align_up((size_t)S * S, 64)) * sizeof(float);
+}
+
+extern "C" int stv_lbfgsc_step(float* x, const float* grad, void* state, void* workspace, size_t n, int history,
+                               int m_max, float lr, float tol_grad, float tol_change, void* stream) {
+  if (!x) return STV_ERR_ARG;
+  const int rc = stv_lbfgsc_dots(grad, state, workspace, n, history, m_max, stream);
+  if (rc != STV_OK) return rc;
+  return stv_lbfgsc_apply(x, grad, state, workspace, n, history, lr, tol_grad, tol_change, stream);
 }
 
 #ifdef STV_SOLVE_STAMPS

@@ -401,6 +401,33 @@ def lbfgs_step(x: torch.Tensor, grad: torch.Tensor, state: torch.Tensor, work: t
                   tol_grad, tol_change, _stream()), "stv_lbfgsc_step" if compact else "stv_lbfgs_step")
 
 
+def lbfgs_dots(grad: torch.Tensor, state: torch.Tensor, work: torch.Tensor, history: int, m_max: int) -> torch.Tensor:
+    """First half of a compact L-BFGS step (stv_lbfgsc_dots): this shard's partial inner products.
+    Returns a float64 VIEW into ``work`` (5*128 + 8 entries) for the caller to all-reduce."""
+    lib = _lib.load()
+    n = grad.numel()
+    _lib.check(lib.stv_lbfgsc_dots(_ptr(grad), _ptr(state), _ptr(work), n, history, m_max, _stream()), "stv_lbfgsc_dots")
+    return lbfgs_dots_view(work, n, history)[0]
+
+
+def lbfgs_dots_view(work: torch.Tensor, n: int, history: int) -> tuple[torch.Tensor, int]:
+    """(float64 view of the step's inner products inside ``work``, index of the max|g| entry)."""
+    count, imax = ctypes.c_int(), ctypes.c_int()
+    off = int(_lib.load().stv_lbfgsc_dots_offset(n, history, ctypes.byref(count), ctypes.byref(imax)))
+    if off % 8:
+        msg = "internal: unaligned inner-product block"
+        raise RuntimeError(msg)
+    return work[off // 4: off // 4 + 2 * count.value].view(torch.float64), imax.value
+
+
+def lbfgs_apply(x: torch.Tensor, grad: torch.Tensor, state: torch.Tensor, work: torch.Tensor, history: int, lr: float,
+                tol_grad: float = 1e-7, tol_change: float = 1e-9) -> None:
+    """Second half (stv_lbfgsc_apply): scalar recursion from the (all-reduced) inner products, then the update."""
+    lib = _lib.load()
+    _lib.check(lib.stv_lbfgsc_apply(_ptr(x), _ptr(grad), _ptr(state), _ptr(work), x.numel(), history, lr, tol_grad,
+                                    tol_change, _stream()), "stv_lbfgsc_apply")
+
+
 def adam_step(x: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, step: int,
               lr: float = 1e-3, betas: tuple[float, float] = (0.9, 0.999), eps: float = 1e-8) -> None:
     b1, b2 = betas

@@ -33,7 +33,12 @@ class HipLBFGS(torch.optim.Optimizer):
 
     def __init__(self, params, lr: float = 1.0, max_iter: int = 1, max_eval: int | None = None,
                  tolerance_grad: float = 1e-7, tolerance_change: float = 1e-9,
-                 history_size: int = 100) -> None:
+                 history_size: int = 100, *, shard_group=None) -> None:
+        """``shard_group`` (a ``torch.distributed`` group, or ``True`` for the default one): the tensor
+        is ONE SHARD of the optimised image (row strips of one large image).  L-BFGS is the same
+        update on every shard once its inner products are summed over the shards, so each step
+        all-reduces the ~650 doubles of the dot-product table (SUM; max|g| with MAX) between the two
+        history sweeps - no vector ever crosses a link."""
         if lr < 0.0:
             msg = f"Invalid learning rate: {lr}"
             raise ValueError(msg)
@@ -53,6 +58,10 @@ class HipLBFGS(torch.optim.Optimizer):
         # "compact": history read twice per step (inner-product tables); "twoloop": torch's
         # operation order, 2m dependent passes.  Same state machine, rounding-level differences.
         self._compact = os.environ.get("STV_LBFGS", "compact") != "twoloop"
+        self._shard_group = shard_group
+        if shard_group is not None and not self._compact:
+            msg = "a sharded image needs the inner-product form of L-BFGS (STV_LBFGS=compact)"
+            raise ValueError(msg)
         self._dev_state, self._work = ops.lbfgs_alloc(p.numel(), history_size, p.device, compact=self._compact)
         self._steps = 0
 
@@ -66,9 +75,21 @@ class HipLBFGS(torch.optim.Optimizer):
             grad = torch.zeros_like(self._p)
         if not grad.is_contiguous():
             grad = grad.contiguous()
-        ops.lbfgs_step(self._p, grad, self._dev_state, self._work, g["history_size"],
-                       min(self._steps, g["history_size"]), float(g["lr"]), g["tolerance_grad"],
-                       g["tolerance_change"], compact=self._compact)
+        m_max = min(self._steps, g["history_size"])
+        if self._shard_group is None:
+            ops.lbfgs_step(self._p, grad, self._dev_state, self._work, g["history_size"], m_max, float(g["lr"]),
+                           g["tolerance_grad"], g["tolerance_change"], compact=self._compact)
+        else:
+            import torch.distributed as dist  # noqa: PLC0415
+            group = None if self._shard_group is True else self._shard_group
+            dots = ops.lbfgs_dots(grad, self._dev_state, self._work, g["history_size"], m_max)
+            imax = ops.lbfgs_dots_view(self._work, self._p.numel(), g["history_size"])[1]
+            gmax = dots[imax:imax + 1].clone()
+            dist.all_reduce(gmax, op=dist.ReduceOp.MAX, group=group)
+            dist.all_reduce(dots, op=dist.ReduceOp.SUM, group=group)
+            dots[imax:imax + 1].copy_(gmax)
+            ops.lbfgs_apply(self._p, grad, self._dev_state, self._work, g["history_size"], float(g["lr"]),
+                            g["tolerance_grad"], g["tolerance_change"])
         self._steps += 1
         return loss
 

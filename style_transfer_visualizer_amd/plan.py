@@ -100,8 +100,15 @@ class Schedule:
     """Buffers + forward/backward op lists for one image size."""
 
     def __init__(self, layers: list[nn.Module], style_at: list[int], content_at: list[int],
-                 H: int, W: int, dtype: torch.dtype, device: torch.device, *, with_grad: bool) -> None:
+                 H: int, W: int, dtype: torch.dtype, device: torch.device, *, with_grad: bool, halo: int = 0) -> None:
+        """``halo`` = 1: the schedule of one ROW STRIP of a larger image (spatial.py).  ``H`` is the
+        strip's own row count; every activation (and the image) carries ``halo`` extra rows above and
+        below that the owner fills before each 3x3 convolution reads them (neighbour's rows, or zeros
+        at the image border).  Convolutions run over the whole buffer - their output in the halo
+        rows is meaningless and is replaced by the next exchange - while pooling works on the
+        strip's own rows only (strip heights are multiples of 16, so no window straddles two strips)."""
         self.H, self.W, self.dtype, self.device = H, W, dtype, device
+        self.halo = halo
         self.nodes: list[Node] = []
         self.style_taps: list[Tap] = []
         self.content_taps: list[Tap] = []
@@ -111,8 +118,15 @@ class Schedule:
 
     # ------------------------------------------------------------------ forward walk
     def _new_buf(self, H: int, W: int, C: int) -> Buf:
+        if self.halo:
+            act = torch.zeros(H + 2 * self.halo, W, C, device=self.device, dtype=self.dtype)
+            return Buf(H + 2 * self.halo, W, C, act)
         act = torch.empty(H, W, C, device=self.device, dtype=self.dtype)
         return Buf(H, W, C, act)
+
+    def interior(self, t: torch.Tensor) -> torch.Tensor:
+        """The strip's own rows of an NHWC buffer (the whole buffer without halos)."""
+        return t[self.halo:t.shape[0] - self.halo] if self.halo else t
 
     def _lower_forward(self, layers: list[nn.Module], style_at: list[int], content_at: list[int]) -> None:
         tapped = set(style_at) | set(content_at)
@@ -214,7 +228,7 @@ class Schedule:
         """Forward schedule; ``after_node(node)`` may return extra ops to splice in right after a
         node's op (loss-side work that only needs that node's output)."""
         out = []
-        fuse_pool = os.environ.get("STV_FUSE_POOL", "1") != "0"      # A/B knob
+        fuse_pool = os.environ.get("STV_FUSE_POOL", "1") != "0" and not self.halo     # A/B knob; strips pool their own rows
         fused: set[int] = set()          # pool nodes whose work rides in the preceding conv's epilogue
         for k, nd in enumerate(self.nodes):
             d = nd.dst
@@ -244,7 +258,8 @@ class Schedule:
                                     q2=nxt.idx if pool_dst is not None else None, H=d.H,
                                     W=d.W, cin=nd.cin, cout=d.C, taps=9, flags=flags))
             elif nd.kind == "pool":
-                out.append(self._op(op=OP_POOL_FWD, p0=nd.src.act, q0=d.act, H=nd.src.H, W=nd.src.W, cin=d.C))
+                src_i = self.interior(nd.src.act)
+                out.append(self._op(op=OP_POOL_FWD, p0=src_i, q0=self.interior(d.act), H=src_i.shape[0], W=nd.src.W, cin=d.C))
             else:
                 out.append(self._op(op=OP_RELU_FWD, p0=nd.src.act, q0=d.act, n=d.act.numel()))
             if after_node is not None:
@@ -291,8 +306,8 @@ class Schedule:
 
     def alloc_grads(self) -> None:
         for nd in self.nodes:
-            if nd.dst.grad is None:
-                nd.dst.grad = torch.empty_like(nd.dst.act)
+            if nd.dst.grad is None:      # strips: halo rows are read before anything wrote them -> start finite
+                nd.dst.grad = torch.zeros_like(nd.dst.act) if self.halo else torch.empty_like(nd.dst.act)
 
     def backward_ops(self, x_grad: torch.Tensor, *, style_coef: float, content_coef: float,
                      coef_dev: torch.Tensor | None) -> list[StvOp]:
@@ -358,8 +373,9 @@ class Schedule:
                     out.append(self._op(op=OP_POOL_BWD, p0=nd.idx, p1=d.grad, q0=s.grad, H=s.H, W=s.W, cin=s.C,
                                         flags=flags | POOL_IDX))
                 else:
-                    out.append(self._op(op=OP_POOL_BWD, p0=s.act, p1=d.grad, q0=s.grad, H=s.H, W=s.W, cin=s.C,
-                                        flags=flags))
+                    s_i = self.interior(s.act)
+                    out.append(self._op(op=OP_POOL_BWD, p0=s_i, p1=self.interior(d.grad), q0=self.interior(s.grad),
+                                        H=s_i.shape[0], W=s.W, cin=s.C, flags=flags))
             else:  # materialised relu
                 out.append(self._op(op=OP_RELU_BWD, p0=s.act, p1=d.grad, q0=s.grad, n=s.act.numel(),
                                     flags=acc_flag(s)))

@@ -1,8 +1,10 @@
 """Row-strip partition of one image (BASELINE configs[4] pattern) vs the single-GPU path.
 
 Two ranks (gloo, both on cuda:0 - this box has one GPU; on a node the same code runs over
-RCCL) split a 512x96 image into strips with recomputed halos; losses and the image gradient
-must equal the unsharded HIP result to fp32 rounding, and three Adam steps must give the same image.
+RCCL) split a 512x96 image into strips.  Two partitions: ``HaloShard`` (a 1-row halo exchanged
+before every 3x3 convolution, Adam and L-BFGS with all-reduced inner products) and the older
+``SpatialShard`` (recomputed 160-row halos, Adam).  Losses and the image gradient must equal the
+unsharded HIP result to fp32 rounding, and three optimizer steps must give the same image.
 """
 from __future__ import annotations
 
@@ -97,3 +99,79 @@ def test_two_strips_equal_the_unsharded_result():
         err = float((grads[r] - g_ref[:, :, c0:c1]).abs().max()) / gscale
         assert err < 2e-5, f"rank {r}: core gradient differs from the unsharded one by {err:.2e}"
         assert float((x_fin - x_ref).abs().max()) < 1e-4, f"rank {r}: image after 3 Adam steps differs"  # lr 1e-2 x normalised update
+
+
+# ------------------------------------------------------------------------------ per-layer halo exchange
+def _halo_worker(rank: int, world: int, port: int, q) -> None:
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from style_transfer_visualizer_amd import spatial
+    model, content, x0, dev = _setup()
+    out = {}
+    for opt_name, lr in (("adam", 1e-2), ("lbfgs", 1.0)):
+        shard = spatial.HaloShard(model._layers(), S_AT, C_AT, content, model.style_targets,
+                                  dtype=torch.float32, style_w=1e5, content_w=1.0)
+        shard.set_image(x0)
+        scores = shard.loss_and_grad()
+        out[f"{opt_name}_scores"] = scores.cpu().numpy()
+        out[f"{opt_name}_grad"] = shard.g_core.cpu().numpy()
+        per_step = []
+        for _ in range(3):
+            per_step.append(shard.step(opt_name, lr=lr).cpu().numpy())
+        out[f"{opt_name}_step_scores"] = per_step
+        out[f"{opt_name}_image"] = shard.gather_image().cpu().numpy()
+        out["rows"] = (shard.c0, shard.c1)
+        out["exchanges"] = shard.exchanges_per_closure
+    torch.cuda.synchronize()
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_halo_exchange_strips_equal_the_unsharded_result_adam_and_lbfgs():
+    import numpy as np
+
+    from style_transfer_visualizer_amd import optimizers
+    model, content, x0, dev = _setup()
+    x = x0.clone().requires_grad_(True)
+    s_ref, c_ref, t_ref = model.loss_and_grad(x, 1e5, 1.0)
+    g_ref = x.grad.clone().cpu()
+    ref_scores = torch.stack((s_ref, c_ref, t_ref)).cpu()
+    refs = {}
+    for name, make in (("adam", lambda p: optimizers.HipAdam([p], lr=1e-2)), ("lbfgs", lambda p: optimizers.HipLBFGS([p], lr=1.0))):
+        xa = x0.clone().requires_grad_(True)
+        opt = make(xa)
+        totals = []
+        for _ in range(3):
+            totals.append(float(opt.step(lambda: model.loss_and_grad(xa, 1e5, 1.0)[2])))
+        refs[name] = (xa.detach().cpu(), totals)
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_halo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert got[0]["rows"] == (0, 256) and got[1]["rows"] == (256, 512)
+    # 13 convs forward + 13 backward: one exchange each (26 per closure)
+    assert got[0]["exchanges"] == 26
+    gscale = float(g_ref.abs().max())
+    for r in (0, 1):
+        c0, c1 = got[r]["rows"]
+        for name in ("adam", "lbfgs"):
+            scores = torch.from_numpy(got[r][f"{name}_scores"])
+            assert torch.allclose(scores, ref_scores, rtol=2e-5, atol=0), f"rank {r} {name}: {scores} vs {ref_scores}"
+            err = float((torch.from_numpy(got[r][f"{name}_grad"]) - g_ref[:, :, c0:c1]).abs().max()) / gscale
+            assert err < 2e-5, f"rank {r}: own-rows gradient differs from the unsharded one by {err:.2e}"
+            x_ref, totals = refs[name]
+            step_totals = [float(sv[2]) for sv in got[r][f"{name}_step_scores"]]
+            np.testing.assert_allclose(step_totals, totals, rtol=1e-4)
+            x_fin = torch.from_numpy(got[r][f"{name}_image"])
+            dev_img = float((x_fin - x_ref).abs().max() / x_ref.abs().max())
+            assert dev_img < 2e-4, f"rank {r} {name}: image after 3 steps differs by {dev_img:.2e} of its range"
+    # both ranks hold the same gathered image
+    assert np.array_equal(got[0]["lbfgs_image"], got[1]["lbfgs_image"])
