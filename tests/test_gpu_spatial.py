@@ -120,6 +120,8 @@ def _halo_worker(rank: int, world: int, port: int, q) -> None:
             per_step.append(shard.step(opt_name, lr=lr).cpu().numpy())
         out[f"{opt_name}_step_scores"] = per_step
         out[f"{opt_name}_image"] = shard.gather_image().cpu().numpy()
+        if opt_name == "lbfgs":
+            out["lbfgs_state"] = shard._opt.device_state()
         out["rows"] = (shard.c0, shard.c1)
         out["exchanges"] = shard.exchanges_per_closure
     torch.cuda.synchronize()
@@ -145,6 +147,8 @@ def test_halo_exchange_strips_equal_the_unsharded_result_adam_and_lbfgs():
         for _ in range(3):
             totals.append(float(opt.step(lambda: model.loss_and_grad(xa, 1e5, 1.0)[2])))
         refs[name] = (xa.detach().cpu(), totals)
+        if name == "lbfgs":
+            ref_state = opt.device_state()
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -169,9 +173,21 @@ def test_halo_exchange_strips_equal_the_unsharded_result_adam_and_lbfgs():
             assert err < 2e-5, f"rank {r}: own-rows gradient differs from the unsharded one by {err:.2e}"
             x_ref, totals = refs[name]
             step_totals = [float(sv[2]) for sv in got[r][f"{name}_step_scores"]]
-            np.testing.assert_allclose(step_totals, totals, rtol=1e-4)
+            # Losses 1 and 2 are evaluated at x0 and x0 - t*g: identical arithmetic.  From the third
+            # evaluation on L-BFGS has used a curvature pair: its update is built from DIFFERENCES of fp32
+            # inner products, and the sharded sums (per-strip partials, then added) are ordered differently
+            # from the unsharded ones - the 1e-4-of-range effect tests/test_gpu_fullsize.py documents
+            # against float64.  Adam has no such cancellation.
+            np.testing.assert_allclose(step_totals[:2], totals[:2], rtol=1e-5)
+            np.testing.assert_allclose(step_totals[2:], totals[2:], rtol=1e-5 if name == "adam" else 2e-3)
             x_fin = torch.from_numpy(got[r][f"{name}_image"])
             dev_img = float((x_fin - x_ref).abs().max() / x_ref.abs().max())
-            assert dev_img < 2e-4, f"rank {r} {name}: image after 3 steps differs by {dev_img:.2e} of its range"
-    # both ranks hold the same gathered image
+            bound = 2e-4 if name == "adam" else 2e-3
+            assert dev_img < bound, f"rank {r} {name}: image after 3 steps differs by {dev_img:.2e} of its range"
+    # both ranks hold the same gathered image, and ran the SAME scalar recursion: after the all-reduce
+    # the inner products are bit-identical on every rank, so the optimizer state must be too
     assert np.array_equal(got[0]["lbfgs_image"], got[1]["lbfgs_image"])
+    assert got[0]["lbfgs_state"] == got[1]["lbfgs_state"]
+    st = got[0]["lbfgs_state"]
+    assert (st["n_iter"], st["hist_len"], st["skip"]) == (ref_state["n_iter"], ref_state["hist_len"], ref_state["skip"]) == (3, 2, 0)
+    assert st["H_diag"] == pytest.approx(ref_state["H_diag"], rel=1e-3)
