@@ -47,7 +47,8 @@ enum {
   STV_MASK = 4,      /* multiply result by (ref > 0): ReLU backward */
   STV_ACCUM = 8,     /* out += result instead of out = result */
   STV_W_BLOCKED = 16, /* conv weights are K-blocked: [taps][cin/CK][cout][CK], CK = 32 bytes of `dtype` */
-  STV_POOL_IDX = 32   /* stv_maxpool_bwd: `x` is the arg-max byte map of stv_conv_igemm_pool, not the activation */
+  STV_POOL_IDX = 32,  /* stv_maxpool_bwd: `x` is the arg-max byte map of stv_conv_igemm_pool, not the activation */
+  STV_POOL_ROUTE = 64 /* stv_op_t only: the CONV op is stv_conv_igemm_route (p2 = arg-max map, q1 = routed output) */
 };
 
 int stv_version(void);
@@ -131,6 +132,18 @@ int stv_conv_igemm_pool(const void* x, const void* w, const float* bias, void* y
 int stv_conv_igemm_dual(const void* x, const void* w, const void* x2, const void* w2, const void* ref,
                         void* y, int H, int W, int cin, int cin2, int cout, int flags, int dtype,
                         void* stream);
+
+/* Input gradient of the conv BEHIND a MaxPool2d(2,2), with the pooling backward folded into its epilogue:
+ *   y_full[2H][2W][cout] <- route( conv3x3(x, w) )   (x = dy of that conv, w = its flipped/transposed weights)
+ * every computed element goes to the position of its window's first maximum, as recorded by
+ * stv_conv_igemm_pool in `pool_idx` ([H][W][cout] bytes), and - with STV_MASK - only where that maximum was
+ * positive (the ReLU mask of the pre-pool activation, bit 2 of the byte); the other three positions of the
+ * window receive zeros.  Replaces convolution_backward + max_pool2d_backward + threshold_backward of
+ * `loss.backward()` (optimization.py:313) for that pair of layers, without the pooled-resolution gradient
+ * ever being stored.  bf16 only, matrix-core shapes only, even 2H x 2W (the caller falls back to
+ * stv_conv_igemm + stv_maxpool_bwd otherwise).  flags: MASK, W_BLOCKED. */
+int stv_conv_igemm_route(const void* x, const void* w, const void* pool_idx, void* y_full, int H, int W, int cin,
+                         int cout, int flags, int dtype, void* stream);
 
 /* Which tile the dispatcher picks for a shape: -1 = scalar fallback (channel counts not a
  * multiple of the MFMA K-slice), else 0..3 = {8x128, 8x64, 4x128, 4x64} (rows x couts) and

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STV_LIB_PATH") or os.path.join(_HERE, "libstv_hip.so")   # override: diagnostic builds
 
 STV_F32, STV_BF16 = 0, 1
-RELU_IN, RELU_OUT, MASK, ACCUM, W_BLOCKED, POOL_IDX = 1, 2, 4, 8, 16, 32
+RELU_IN, RELU_OUT, MASK, ACCUM, W_BLOCKED, POOL_IDX, POOL_ROUTE = 1, 2, 4, 8, 16, 32, 64
 LANE_SIDE, LANE_JOIN = 1 << 29, 1 << 30          # scheduling hints of the command-buffer executor
 
 (OP_CONV_FIRST_FWD, OP_CONV_FIRST_DGRAD, OP_CONV, OP_POOL_FWD, OP_POOL_BWD, OP_RELU_FWD,
@@ -65,6 +65,7 @@ SIGNATURES = {
     "stv_conv_igemm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "stv_conv_igemm_pool": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                     c_void_p]),
+    "stv_conv_igemm_route": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "stv_conv_igemm_dual": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                     c_int, c_int, c_int, c_void_p]),
     "stv_conv_tune": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -16,6 +16,11 @@ struct ConvArgs {
   const void* x2;
   const void* w2;
   int cin2;
+  // optional (bf16 dgrad in front of a max-pool, stv_conv_igemm_route): instead of storing y, route every
+  // element to its window's arg-max position in route_out [2H][2W][cout] (zeros elsewhere), reading the
+  // forward pass's arg-max byte map route_idx [H][W][cout] - MaxPool2d's backward without a pass of its own
+  const void* route_idx = nullptr;
+  void* route_out = nullptr;
 };
 
 // conv_ws.hip: weight-stationary persistent kernel for 3x3, Cin = 64, bf16 (the short-K layers).

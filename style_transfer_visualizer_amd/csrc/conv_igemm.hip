@@ -447,13 +447,18 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
   // 16-byte stores per 32 channels, no LDS round trip and no barrier.  Only the K-split variant
   // still meets in LDS (the second group's partial sums).
   const bool relu_out = (a.flags & STV_RELU_OUT) != 0;
-  const bool do_mask = (a.flags & STV_MASK) != 0 && !mask_done;
+  const bool do_mask = (a.flags & STV_MASK) != 0 && !mask_done && a.route_out == nullptr;
   const bool do_acc = (a.flags & STV_ACCUM) != 0;
   const int out_bytes = a.H * a.W * a.cout * (int)sizeof(T);
   const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, out_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_ref = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<void*>(a.ref), 0, do_mask ? out_bytes : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_old = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, do_acc ? out_bytes : 0, 0x00020000);
+  const bool route = sizeof(T) == 2 && a.route_out != nullptr;
+  const bool route_mask = (a.flags & STV_MASK) != 0 && route;        // with a route, MASK names the pre-pool ReLU
+  const __amdgpu_buffer_rsrc_t rs_ridx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(a.route_idx), 0, route ? a.H * a.W * a.cout : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_route = __builtin_amdgcn_make_buffer_rsrc(a.route_out, 0, route ? 4 * out_bytes : 0, 0x00020000);
 
   if (C::KS == 2) {               // the second K group hands its partial sums over through LDS
     float* cs = reinterpret_cast<float*>(smem);
@@ -553,7 +558,33 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
                 const s16x8 keep = (s16x8)(m > (s16x8)(short)0);          // 0xFFFF where ref > 0
                 out = __builtin_bit_cast(u32x4, __builtin_bit_cast(s16x8, out) & keep);
               }
-              __builtin_amdgcn_raw_buffer_store_b128(out, rs_out, off, 0, 0);
+              if (route) {
+                // MaxPool2d backward in place of the store: this lane's 8 channels of pooled pixel (gy, gx)
+                // go to the window position their arg-max byte names (bits 0-1; bit 2 = the winner was
+                // positive, i.e. the ReLU mask of the pre-pool map), zeros to the other three positions.
+                const uint32_t ioff = off != kOob ? (off >> 1) : kOob;       // byte map: same element index
+                const auto ib = __builtin_amdgcn_raw_buffer_load_b64(rs_ridx, ioff, 0, 0);
+                const int gy = y0 + wm * C::MT + mt, gx = x0 + r;            // (only the full-resolution map is ever routed)
+                const uint32_t base = (uint32_t)((((2 * gy) * (2 * a.W) + 2 * gx) * a.cout + nn) * 2);
+#pragma unroll
+                for (int pos = 0; pos < 4; ++pos) {
+                  uint32_t keep[4];
+#pragma unroll
+                  for (int half = 0; half < 2; ++half) {
+                    // bytes equal to the wanted code -> 0xFF (codes are < 8: the zero-byte test is exact)
+                    const uint32_t want = route_mask ? 0x01010101u * (uint32_t)(pos | 4) : 0x01010101u * (uint32_t)pos;
+                    const uint32_t x = (route_mask ? ib[half] : (ib[half] & 0x03030303u)) ^ want;
+                    const uint32_t hit = (((x - 0x01010101u) & ~x & 0x80808080u) >> 7) * 0xFFu;
+                    keep[2 * half] = __builtin_amdgcn_perm(hit, hit, 0x01010000u);       // channels 0,1 of this half
+                    keep[2 * half + 1] = __builtin_amdgcn_perm(hit, hit, 0x03030202u);   // channels 2,3
+                  }
+                  const u32x4 v = {out[0] & keep[0], out[1] & keep[1], out[2] & keep[2], out[3] & keep[3]};
+                  const uint32_t o2 = off != kOob ? base + (uint32_t)((((pos >> 1) * 2 * a.W + (pos & 1)) * a.cout) * 2) : kOob;
+                  __builtin_amdgcn_raw_buffer_store_b128(v, rs_route, o2, 0, 0);
+                }
+              } else {
+                __builtin_amdgcn_raw_buffer_store_b128(out, rs_out, off, 0, 0);
+              }
             }
           }
         }
@@ -900,6 +931,21 @@ extern "C" int stv_conv_igemm_pool(const void* x, const void* w, const float* bi
   ConvArgs a{x, w, bias, nullptr, y, H, W, cin, cout, flags, y_pool, pool_idx, nullptr, nullptr, 0};
   hipStream_t st = static_cast<hipStream_t>(stream);
   return dtype == STV_F32 ? launch_typed<float, 9>(a, st) : launch_typed<bf16_t, 9>(a, st);
+}
+
+extern "C" int stv_conv_igemm_route(const void* x, const void* w, const void* pool_idx, void* y_full, int H, int W, int cin,
+                                    int cout, int flags, int dtype, void* stream) {
+  if (!x || !w || !pool_idx || !y_full || H <= 0 || W <= 0 || cin <= 0 || cout <= 0) return STV_ERR_ARG;
+  if (dtype != STV_BF16) return STV_ERR_ARG;                                   // packed-word routing: bf16 storage only
+  if (flags & (STV_RELU_IN | STV_RELU_OUT | STV_ACCUM)) return STV_ERR_ARG;
+  if ((size_t)4 * H * W * (size_t)(cin > cout ? cin : cout) * 2 >= (size_t)1 << 31) return STV_ERR_ARG;
+  if (choose_cfg(H, W, cin, cout, 2, 9) < 0) return STV_ERR_ARG;
+  ConvArgs a{x, w, nullptr, nullptr, y_full, H, W, cin, cout, flags, nullptr, nullptr, nullptr, nullptr, 0};
+  a.route_idx = pool_idx;
+  a.route_out = y_full;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int cfg = choose_cfg(H, W, cin, cout, 2, 9);
+  return launch_mfma<bf16_t, 9>(a, cfg, st);                                   // always the general kernel
 }
 
 extern "C" int stv_conv_igemm_dual(const void* x, const void* w, const void* x2, const void* w2, const void* ref,

@@ -38,6 +38,8 @@ int run_op(const stv_op_t& op, void* st) {
       return stv_conv_first_dgrad(o.p0, static_cast<const float*>(o.p1), static_cast<float*>(o.q0), o.H,
                                   o.W, o.cin, o.cout, o.dtype, st);
     case STV_OP_CONV:
+      if (o.flags & STV_POOL_ROUTE)   // dgrad in front of a max-pool: p2 = arg-max byte map, q1 = full-resolution gradient
+        return stv_conv_igemm_route(o.p0, o.p1, o.p2, o.q1, o.H, o.W, o.cin, o.cout, o.flags & ~STV_POOL_ROUTE, o.dtype, st);
       if (o.q2 && o.q3)   // dgrad with the Gram-backward 1x1 term of the same output fused in (q2 = x2, q3 = w2, n = cin2)
         return stv_conv_igemm_dual(o.p0, o.p1, o.q2, o.q3, o.p3, o.q0, o.H, o.W, o.cin, (int)o.n, o.cout,
                                    o.flags, o.dtype, st);

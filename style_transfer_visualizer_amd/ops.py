@@ -214,6 +214,24 @@ def conv_igemm_dual(x: torch.Tensor, w: torch.Tensor, x2: torch.Tensor, w2: torc
     return out
 
 
+def conv_igemm_route(dy: torch.Tensor, w: torch.Tensor, pool_idx: torch.Tensor, out: torch.Tensor | None = None,
+                     flags: int = 0) -> torch.Tensor:
+    """dgrad of the conv behind a max-pool with the pooling backward in its epilogue (stv_conv_igemm_route):
+    dy [H,W,Cin], w backward-packed, pool_idx [H,W,Cout] uint8 -> routed gradient [2H,2W,Cout]."""
+    H, W, cin = dy.shape
+    if w.dim() == 4:
+        _, nck, cout, ck = w.shape
+        flags |= W_BLOCKED
+    else:
+        _, cout, _ = w.shape
+    if out is None:
+        out = torch.empty(2 * H, 2 * W, cout, device=dy.device, dtype=dy.dtype)
+    lib = _lib.load()
+    _lib.check(lib.stv_conv_igemm_route(_ptr(dy), _ptr(w), _ptr(pool_idx), _ptr(out), H, W, cin, cout, flags,
+                                        dtype_code(dy.dtype), _stream()), "stv_conv_igemm_route")
+    return out
+
+
 def gram_multi(feats: list[torch.Tensor], targets: list[torch.Tensor], *, coef: float = 1.0,
                clamp_max: float = 5e5) -> tuple[list[torch.Tensor], list[torch.Tensor], list[torch.Tensor]]:
     """Batched Gram chain (stv_gram_multi) over NHWC feature maps: returns (grams, loss partials, seeds) per tap."""

@@ -27,7 +27,7 @@ import torch
 from torch import nn
 
 from . import _lib, ops
-from ._lib import (ACCUM, MASK, POOL_IDX, W_BLOCKED, OP_GRAM_MULTI, OP_CONTENT_GRAD, OP_CONTENT_LOSS, OP_CONV, OP_CONV_FIRST_DGRAD,
+from ._lib import (ACCUM, MASK, POOL_IDX, POOL_ROUTE, W_BLOCKED, OP_GRAM_MULTI, OP_CONTENT_GRAD, OP_CONTENT_LOSS, OP_CONV, OP_CONV_FIRST_DGRAD,
                    OP_CONV_FIRST_FWD, OP_GRAM_FINISH, OP_GRAM_PARTIAL, OP_LOSS_COMBINE, OP_POOL_BWD,
                    OP_POOL_FWD, OP_RELU_BWD, OP_RELU_FWD, RELU_IN, RELU_OUT, StvOp)
 
@@ -323,8 +323,13 @@ class Schedule:
         n_style = len(self.style_taps)
         fuse_gram = os.environ.get("STV_FUSE_GRAM", "1") != "0"      # A/B knob
         fused_taps: set[int] = set()     # style taps whose dF = F.S rides in the dgrad that shares their buffer
+        fuse_route = os.environ.get("STV_FUSE_POOL_BWD", "1") != "0"      # A/B knob
+        routed: set[int] = set()         # pool nodes whose backward rides in the dgrad of the conv behind them
+        producer = {id(n.dst): n for n in self.nodes}
         for nd in reversed(self.nodes):
             d = nd.dst
+            if id(nd) in routed:         # its consumer's dgrad already wrote nd.src.grad
+                continue
             for tap in d.taps:
                 if id(tap) in fused_taps:
                     continue
@@ -359,6 +364,23 @@ class Schedule:
                 if (fuse_gram and nd.wb.dim() == 4 and s.act.is_cuda and not (s.relu_fused and s.taps)
                         and s.C % (32 // s.act.element_size()) == 0):
                     gram = next((t for t in s.taps if t.kind == "style" and t.sgrad is not None), None)
+                # s is a pooled map (arg-max byte map available, nothing else contributes to its gradient):
+                # the dgrad's epilogue routes straight into the pre-pool gradient - no pooled-resolution
+                # gradient, no pooling-backward pass
+                pool_nd = producer.get(id(s))
+                if (fuse_route and gram is None and pool_nd is not None and pool_nd.kind == "pool" and pool_nd.idx is not None
+                        and self.dtype == torch.bfloat16 and nd.wb.dim() == 4 and not s.taps and not mask_src
+                        and id(s) not in written and pool_nd.src.H == 2 * s.H and pool_nd.src.W == 2 * s.W
+                        and id(pool_nd.src) not in written
+                        and 4 * s.act.numel() * s.act.element_size() < 2 ** 31):
+                    ps = pool_nd.src
+                    rflags = (MASK if (ps.relu_fused and not ps.taps) else 0) | W_BLOCKED | POOL_ROUTE
+                    out.append(self._op(op=OP_CONV, p0=d.grad, p1=nd.wb, p2=pool_nd.idx, q1=ps.grad, H=s.H, W=s.W,
+                                        cin=d.C, cout=s.C, taps=9, flags=rflags))
+                    routed.add(id(pool_nd))
+                    written.add(id(s))
+                    written.add(id(ps))
+                    continue
                 if gram is not None:
                     fused_taps.add(id(gram))
                     out.append(self._op(op=OP_CONV, p0=d.grad, p1=nd.wb, p3=s.act if mask_src else None, q0=s.grad,

@@ -256,6 +256,37 @@ def test_conv_ws_forward_pool_and_backward(case, monkeypatch):
         assert_close(ops.from_nhwc(out), xr.grad * (zq > 0).float(), dtype, 9 * 64, f"ws masked dgrad {case}")
 
 
+@pytest.mark.parametrize("cfg", [None, 0, 1, 3, 4, 5, 7, 8])
+@pytest.mark.parametrize("case", [(128, 64, 32, 64), (256, 128, 16, 40), (512, 512, 8, 8), (512, 256, 12, 20)])
+def test_conv_igemm_route_equals_dgrad_then_pool_backward(cfg, case, monkeypatch):
+    """stv_conv_igemm_route: the dgrad of the conv behind a max-pool writes the pre-pool gradient directly.
+    Must equal, bit for bit, the two launches it replaces (same dgrad arithmetic, then the arg-max routing
+    of stv_maxpool_bwd with and without the ReLU mask)."""
+    cd, cs, H, W = case                      # dy channels (the conv's Cout), routed channels (its Cin), pooled size
+    dtype = torch.bfloat16
+    if cfg is not None:
+        if cs <= 64 and cfg in (0, 2):
+            pytest.skip("128-channel tiles need more than 64 output channels")
+        monkeypatch.setenv("STV_CONV_CFG", str(cfg))
+    # a forward conv + pool produces a genuine arg-max map (with ties from the ReLU zeros)
+    xf = rnd((1, 64, 2 * H, 2 * W), 161)
+    wf = rnd((cs, 64, 3, 3), 162, -1, 1) * (2.0 / (9 * 64)) ** 0.5
+    idx = torch.empty(H, W, cs, device=DEV, dtype=torch.uint8)
+    monkeypatch.setenv("STV_CONV_WS", "0")
+    y, _ = ops.conv_igemm_pool(ops.to_nhwc(xf, dtype).to(DEV), ops.block_weights(ops.pack_weights_fwd(wf).to(dtype).to(DEV)),
+                               None, flags=ops.RELU_OUT, pool_idx=idx)
+    w = rnd((cd, cs, 3, 3), 163, -1, 1) * (2.0 / (9 * cd)) ** 0.5
+    wb = ops.block_weights(ops.pack_weights_bwd(w).to(dtype).to(DEV))
+    dy = ops.to_nhwc(rnd((1, cd, H, W), 164), dtype).to(DEV)
+    pooled_grad = ops.conv_igemm(dy, wb, None)
+    for flags in (0, ops.MASK):
+        want = torch.full((2 * H, 2 * W, cs), 7.0, device=DEV, dtype=dtype)
+        ops.maxpool_bwd_idx(idx, pooled_grad, 2 * H, 2 * W, out=want, flags=flags)
+        got = torch.full((2 * H, 2 * W, cs), -3.0, device=DEV, dtype=dtype)
+        ops.conv_igemm_route(dy, wb, idx, out=got, flags=flags)
+        assert torch.equal(got, want), f"route {case} cfg={cfg} flags={flags}"
+
+
 def test_conv_ws_matches_the_general_kernel(monkeypatch):
     """Same stage / tap accumulation order as conv_igemm.hip; only the bias enters first instead of last
     (it initialises the accumulators): the two kernels agree except for rare one-ulp roundings."""

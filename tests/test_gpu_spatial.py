@@ -33,11 +33,15 @@ def _setup():
     from style_transfer_visualizer_amd import core_model, synthetic
     dev = torch.device("cuda:0")
     weights = synthetic.synthetic_conv_weights(3, MINI)
-    core_model.initialize_vgg = lambda: core_model.build_vgg_features(weights, MINI).eval()
     content = synthetic.synthetic_image(0, H, W).to(dev)
     style = synthetic.synthetic_image(1, 96, 128).to(dev)
     x0 = synthetic.synthetic_image(2, H, W).to(dev)
-    model = core_model.StyleContentModel(S_AT, C_AT).to(dev)
+    saved = core_model.initialize_vgg                 # (also runs in spawned workers, where no monkeypatch fixture exists)
+    core_model.initialize_vgg = lambda: core_model.build_vgg_features(weights, MINI).eval()
+    try:
+        model = core_model.StyleContentModel(S_AT, C_AT).to(dev)
+    finally:
+        core_model.initialize_vgg = saved
     model.set_targets(style, content)
     return model, content, x0, dev
 
