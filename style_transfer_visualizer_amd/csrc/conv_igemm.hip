@@ -571,10 +571,12 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
                   uint32_t keep[4];
 #pragma unroll
                   for (int half = 0; half < 2; ++half) {
-                    // bytes equal to the wanted code -> 0xFF (codes are < 8: the zero-byte test is exact)
+                    // bytes equal to the wanted code -> 0xFF.  x < 0x80 per byte, so adding 0x7F sets bit 7
+                    // exactly in the non-zero bytes, without a carry into the neighbour (the subtract-and-
+                    // mask zero-byte test lets a borrow ripple into a byte of value 1)
                     const uint32_t want = route_mask ? 0x01010101u * (uint32_t)(pos | 4) : 0x01010101u * (uint32_t)pos;
                     const uint32_t x = (route_mask ? ib[half] : (ib[half] & 0x03030303u)) ^ want;
-                    const uint32_t hit = (((x - 0x01010101u) & ~x & 0x80808080u) >> 7) * 0xFFu;
+                    const uint32_t hit = ((~(x + 0x7F7F7F7Fu) & 0x80808080u) >> 7) * 0xFFu;
                     keep[2 * half] = __builtin_amdgcn_perm(hit, hit, 0x01010000u);       // channels 0,1 of this half
                     keep[2 * half + 1] = __builtin_amdgcn_perm(hit, hit, 0x03030202u);   // channels 2,3
                   }
