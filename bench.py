@@ -82,16 +82,21 @@ def kernel_group(meta, OP, dtype_code: int = 1) -> str | None:
 
 def pmc_traffic(kernel: str, size: int) -> tuple[int | None, str | None]:
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary of this workload
-    (profiles/r01_pmc_hbm_<size>.json: FETCH_SIZE/WRITE_SIZE in separate passes, FETCH doubled as
+    (profiles/r<NN>_pmc_hbm_<size>.json, newest round: FETCH_SIZE/WRITE_SIZE in separate passes, FETCH doubled as
     MI355X_MICROARCH.md prescribes for gfx950).  bench.py cannot run the profiler itself."""
+    import glob
     import re
-    path = os.path.join(ROOT, "profiles", f"r01_pmc_hbm_{size}.json")
-    if not os.path.exists(path):
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_hbm_{size}.json")))      # newest round last
+    if not found:
         return None, None
+    path = found[-1]
 
     def key(name: str) -> str:
         m = re.search(r"(\w+_kernel|\w+_c64)\W.*?((?:unsigned short|float)?[\d, ]*\d)\s*>", name)
-        return re.sub(r"\s+", "", (m.group(1) + "|" + m.group(2)) if m else name)
+        if m is None:
+            m2 = re.search(r"(conv_ws_kernel<\w+)", name)       # conv_ws_kernel<DG, RELU_IN>: keyed by its first flag
+            return re.sub(r"\s+", "", m2.group(1)) if m2 else re.sub(r"\s+", "", name)
+        return re.sub(r"\s+", "", m.group(1) + "|" + m.group(2))
     try:
         data = json.load(open(path))["kernels"]
     except (OSError, ValueError, KeyError):

@@ -18,7 +18,7 @@ for d in dirs:
         continue
     agg, n, name = collections.defaultdict(float), collections.defaultdict(int), None
     for r in csv.DictReader(open(f[-1])):
-        if "conv_igemm" not in r["Kernel_Name"]:
+        if "conv_igemm" not in r["Kernel_Name"] and "conv_ws" not in r["Kernel_Name"]:
             continue
         name = r["Kernel_Name"]
         agg[r["Counter_Name"]] += float(r["Counter_Value"])
@@ -27,7 +27,8 @@ for d in dirs:
         continue
     raw = {k: int(v / n[k]) for k, v in agg.items()}
     cyc = raw["SQ_BUSY_CYCLES"] / 32
-    key = os.path.basename(d.rstrip("/"))[3:] + " " + name[name.index("Cfg<"):name.index(">(") - 1 if ">(" in name else len(name)]
+    short = name[name.index("Cfg<"):name.index(">(") - 1 if ">(" in name else len(name)] if "Cfg<" in name else name[name.index("conv_ws"):name.index("(", name.index("conv_ws"))]
+    key = os.path.basename(d.rstrip("/"))[3:] + " " + short
     out["kernels"][key] = {
         "launches": max(n.values()),
         "wait_any_frac_of_wave_cycles": round(raw["SQ_WAIT_ANY"] / raw["SQ_WAVE_CYCLES"], 3),
