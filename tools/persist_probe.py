@@ -1,0 +1,23 @@
+"""One-tile vs persistent form of the 8x128 / 8x64 tiles on the deep layer shapes (STV_CONV_CFG forced per call)."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from style_transfer_visualizer_amd import ops
+dev = "cuda"
+def t(fn, n=30):
+    for _ in range(5): fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); e1.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+shapes = [(256, 256, 256), (256, 128, 256), (128, 512, 512), (128, 256, 512), (512, 128, 128), (128, 256, 256), (64, 512, 512)]
+for (H, cin, cout) in shapes:
+    x = (torch.randn(H, H, cin, device=dev) * 0.5).bfloat16()
+    w = ops.block_weights((torch.randn(9, cout, cin, device=dev) * 0.03).bfloat16())
+    b = torch.zeros(cout, device=dev); y = torch.empty(H, H, cout, device=dev, dtype=torch.bfloat16)
+    row = []
+    for cfg in (0, 9, 1, 10):
+        os.environ["STV_CONV_CFG"] = str(cfg)
+        us = t(lambda: ops.conv_igemm(x, w, b, out=y, flags=ops.RELU_OUT))
+        row.append(f"cfg{cfg}: {us:6.1f} us {2*9*cin*cout*H*H/us/1e6:6.0f} TF/s")
+    print(f"{H}^2 {cin}->{cout}: " + " | ".join(row))
