@@ -323,15 +323,122 @@ __device__ __forceinline__ void conv_mainloop(const Phase<typename C::Elem>& ph,
 
 }
 
-// ---- epilogue of one output tile, in registers (shared by the one-tile and the persistent kernel) ----
 template <typename C>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[C::MT][C::NT], const f32x4 (&bias_v)[C::NT][4],
-                                              const Geom& gm, bool mask_done, char* smem) {
+__global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (LDS address-space casts are device-only)
   using T = typename C::Elem;
-  const int lane = gm.lane, grp = gm.grp, wm = gm.wm, wn = gm.wn, r = gm.r, h = gm.h;
-  const int x0 = gm.x0, y0 = gm.y0, n0 = gm.n0;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave_wg = __builtin_amdgcn_readfirstlane(tid >> 6) & (C::NWAVES * C::KS - 1);   // scalar
+  const int grp = wave_wg / C::NWAVES;               // K group
+  const int wave = wave_wg % C::NWAVES;              // wave within the group
+  const int wm = wave / C::WN, wn = wave % C::WN;
+  const int r = lane & 31, h = lane >> 5;
+
+  const int tiles_x = (a.W + C::TW - 1) / C::TW;
+  // Block -> (spatial tile, channel block).  Workgroups are dealt to the 8 XCDs round-robin and each
+  // XCD has its own L2, so the channel blocks of one spatial tile are given ids 8 apart: they run
+  // on the same XCD at about the same time and the second one finds the tile's input in that L2
+  // (with a plain 2-D grid every channel block streamed the whole input from HBM again).
+  const int ntiles = tiles_x * ((a.H + C::TH - 1) / C::TH);
+  const int ny = (a.cout + C::BN - 1) / C::BN;
+  int tile, yb;
+  {
+    const int round = 8 * ny, b = (int)blockIdx.x;
+    const int grp8 = b / round, within = b - grp8 * round;
+    const int left = ntiles - grp8 * 8;                    // tiles in this group of (up to) eight
+    const int span = left < 8 ? left : 8;
+    tile = grp8 * 8 + within % span;
+    yb = within / span;
+  }
+  const int tile_x = tile % tiles_x;
+  const int tile_y = tile / tiles_x;
+  const int x0 = tile_x * C::TW, y0 = tile_y * C::TH;
+  const int n0 = yb * C::BN;
+
+  const T* __restrict__ xin = static_cast<const T*>(a.x);
+  const T* __restrict__ wgt = static_cast<const T*>(a.w);
+  const bool w_blocked = (a.flags & STV_W_BLOCKED) != 0;
+  const int nchunks = a.cin / C::CK;
+  // ReLU-on-load floor: integer max with 0 clears negative elements, with INT_MIN it is the identity
+  const uint32_t relu_floor = (a.flags & STV_RELU_IN) ? 0u : (sizeof(T) == 2 ? 0x80008000u : 0x80000000u);
+  STV_STAMP(0);
+  // Accumulator layout (MFMA roles: rows = output channels, columns = pixels): this lane owns
+  // pixel r of its wave's row blocks and, per 32-channel block, channels 8j + 4h + e (j, e < 4).
+  // Its bias values are requested first: a global round trip is ~2 us on a busy chip.
+  const int wm_ = (wave / C::WN), wn_ = (wave % C::WN);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.bias), 0, a.bias != nullptr ? a.cout * 4 : 0, 0x00020000);
+  f32x4 bias_v[C::NT][4];           // channels past cout (and a null bias) read as zero
+#pragma unroll
+  for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int nn = n0 + wn_ * (C::NT * 32) + nt * 32 + 8 * j + 4 * (lane >> 5);
+      const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (uint32_t)(nn * 4), 0, 0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bias_v[nt][j][e] = __uint_as_float(t[e]);
+    }
+
+  f32x16 acc[C::MT][C::NT];
+#pragma unroll
+  for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.0f;
+
   constexpr uint32_t kOob = 0x80000000u;   // >= num_records for every tensor this kernel accepts
-  (void)lane;
+  const Geom geom{a.H, a.W, a.cout, x0, y0, n0, lane, wave, grp, wm, wn, r, h};
+  const Phase<T> ph1{xin, wgt, a.cin, w_blocked, relu_floor};
+  conv_mainloop<C>(ph1, geom, smem, acc);
+  STV_STAMP(2);
+
+  // ---- fused second term (3x3 kernels only): the ReLU mask belongs to the first term alone, so it
+  // is applied to the accumulators now - `ref` is read in their layout - and the 1x1 product of
+  // (x2, w2) then lands on top, same tile, same registers.  The separate launch it replaces also
+  // had to read-modify-write this output.
+  bool mask_done = false;
+  if constexpr (C::TAPS == 9) {
+    if (a.x2 != nullptr) {
+      if (a.flags & STV_MASK) {
+        const int ref_bytes = a.H * a.W * a.cout * (int)sizeof(T);
+        const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.ref), 0, ref_bytes, 0x00020000);
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt) {
+          const int gy = y0 + wm * C::MT + mt, gx = x0 + r;
+          const bool pok = gy < a.H && gx < a.W;
+#pragma unroll
+          for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int nn = n0 + wn * (C::NT * 32) + nt * 32 + 8 * j + 4 * h;
+              const uint32_t off = (pok && nn < a.cout) ? (uint32_t)((((gy * a.W + gx) * a.cout) + nn) * (int)sizeof(T)) : kOob;
+              if constexpr (sizeof(T) == 4) {
+                const u32x4 m = __builtin_amdgcn_raw_buffer_load_b128(rs_m, off, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[mt][nt][4 * j + e] = (__uint_as_float(m[e]) > 0.0f) ? acc[mt][nt][4 * j + e] : 0.0f;
+              } else {
+                const auto m = __builtin_amdgcn_raw_buffer_load_b64(rs_m, off, 0, 0);
+                acc[mt][nt][4 * j + 0] = ((int)(m[0] << 16) > 0) ? acc[mt][nt][4 * j + 0] : 0.0f;
+                acc[mt][nt][4 * j + 1] = ((int)(m[0] & 0xFFFF0000u) > 0) ? acc[mt][nt][4 * j + 1] : 0.0f;
+                acc[mt][nt][4 * j + 2] = ((int)(m[1] << 16) > 0) ? acc[mt][nt][4 * j + 2] : 0.0f;
+                acc[mt][nt][4 * j + 3] = ((int)(m[1] & 0xFFFF0000u) > 0) ? acc[mt][nt][4 * j + 3] : 0.0f;
+              }
+            }
+        }
+        mask_done = true;
+      }
+      using C1 = Cfg<T, C::TH, C::BN, C::WM, C::WN, 1, C::KS, C::NBUF>;
+      static_assert(C1::RING_BYTES <= C::LDS_BYTES, "the 1x1 pass reuses the 3x3 ring");
+      const Phase<T> ph2{static_cast<const T*>(a.x2), static_cast<const T*>(a.w2), a.cin2, false,
+                         sizeof(T) == 2 ? 0x80008000u : 0x80000000u};
+      conv_mainloop<C1>(ph2, geom, smem, acc);
+    }
+  }
+
   // ---- epilogue, in registers ----------------------------------------------------------------
   // A lane holds, per (row block, 32-channel block), 4 groups of 4 consecutive channels of ONE
   // pixel.  fp32: each group is a 16-byte store as it is.  bf16: a group packs to 8 bytes;
@@ -560,352 +667,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[C
       }
     }
   }
-}
-
-template <typename C>
-__global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
-#if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (LDS address-space casts are device-only)
-  using T = typename C::Elem;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave_wg = __builtin_amdgcn_readfirstlane(tid >> 6) & (C::NWAVES * C::KS - 1);   // scalar
-  const int grp = wave_wg / C::NWAVES;               // K group
-  const int wave = wave_wg % C::NWAVES;              // wave within the group
-  const int wm = wave / C::WN, wn = wave % C::WN;
-  const int r = lane & 31, h = lane >> 5;
-
-  const int tiles_x = (a.W + C::TW - 1) / C::TW;
-  // Block -> (spatial tile, channel block).  Workgroups are dealt to the 8 XCDs round-robin and each
-  // XCD has its own L2, so the channel blocks of one spatial tile are given ids 8 apart: they run
-  // on the same XCD at about the same time and the second one finds the tile's input in that L2
-  // (with a plain 2-D grid every channel block streamed the whole input from HBM again).
-  const int ntiles = tiles_x * ((a.H + C::TH - 1) / C::TH);
-  const int ny = (a.cout + C::BN - 1) / C::BN;
-  int tile, yb;
-  {
-    const int round = 8 * ny, b = (int)blockIdx.x;
-    const int grp8 = b / round, within = b - grp8 * round;
-    const int left = ntiles - grp8 * 8;                    // tiles in this group of (up to) eight
-    const int span = left < 8 ? left : 8;
-    tile = grp8 * 8 + within % span;
-    yb = within / span;
-  }
-  const int tile_x = tile % tiles_x;
-  const int tile_y = tile / tiles_x;
-  const int x0 = tile_x * C::TW, y0 = tile_y * C::TH;
-  const int n0 = yb * C::BN;
-
-  const T* __restrict__ xin = static_cast<const T*>(a.x);
-  const T* __restrict__ wgt = static_cast<const T*>(a.w);
-  const bool w_blocked = (a.flags & STV_W_BLOCKED) != 0;
-  const int nchunks = a.cin / C::CK;
-  // ReLU-on-load floor: integer max with 0 clears negative elements, with INT_MIN it is the identity
-  const uint32_t relu_floor = (a.flags & STV_RELU_IN) ? 0u : (sizeof(T) == 2 ? 0x80008000u : 0x80000000u);
-  STV_STAMP(0);
-  // Accumulator layout (MFMA roles: rows = output channels, columns = pixels): this lane owns
-  // pixel r of its wave's row blocks and, per 32-channel block, channels 8j + 4h + e (j, e < 4).
-  // Its bias values are requested first: a global round trip is ~2 us on a busy chip.
-  const int wm_ = (wave / C::WN), wn_ = (wave % C::WN);
-  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.bias), 0, a.bias != nullptr ? a.cout * 4 : 0, 0x00020000);
-  f32x4 bias_v[C::NT][4];           // channels past cout (and a null bias) read as zero
-#pragma unroll
-  for (int nt = 0; nt < C::NT; ++nt)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int nn = n0 + wn_ * (C::NT * 32) + nt * 32 + 8 * j + 4 * (lane >> 5);
-      const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (uint32_t)(nn * 4), 0, 0);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) bias_v[nt][j][e] = __uint_as_float(t[e]);
-    }
-
-  f32x16 acc[C::MT][C::NT];
-#pragma unroll
-  for (int mt = 0; mt < C::MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < C::NT; ++nt)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.0f;
-
-  constexpr uint32_t kOob = 0x80000000u;   // >= num_records for every tensor this kernel accepts
-  const Geom geom{a.H, a.W, a.cout, x0, y0, n0, lane, wave, grp, wm, wn, r, h};
-  const Phase<T> ph1{xin, wgt, a.cin, w_blocked, relu_floor};
-  conv_mainloop<C>(ph1, geom, smem, acc);
-  STV_STAMP(2);
-
-  // ---- fused second term (3x3 kernels only): the ReLU mask belongs to the first term alone, so it
-  // is applied to the accumulators now - `ref` is read in their layout - and the 1x1 product of
-  // (x2, w2) then lands on top, same tile, same registers.  The separate launch it replaces also
-  // had to read-modify-write this output.
-  bool mask_done = false;
-  if constexpr (C::TAPS == 9) {
-    if (a.x2 != nullptr) {
-      if (a.flags & STV_MASK) {
-        const int ref_bytes = a.H * a.W * a.cout * (int)sizeof(T);
-        const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.ref), 0, ref_bytes, 0x00020000);
-#pragma unroll
-        for (int mt = 0; mt < C::MT; ++mt) {
-          const int gy = y0 + wm * C::MT + mt, gx = x0 + r;
-          const bool pok = gy < a.H && gx < a.W;
-#pragma unroll
-          for (int nt = 0; nt < C::NT; ++nt)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int nn = n0 + wn * (C::NT * 32) + nt * 32 + 8 * j + 4 * h;
-              const uint32_t off = (pok && nn < a.cout) ? (uint32_t)((((gy * a.W + gx) * a.cout) + nn) * (int)sizeof(T)) : kOob;
-              if constexpr (sizeof(T) == 4) {
-                const u32x4 m = __builtin_amdgcn_raw_buffer_load_b128(rs_m, off, 0, 0);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[mt][nt][4 * j + e] = (__uint_as_float(m[e]) > 0.0f) ? acc[mt][nt][4 * j + e] : 0.0f;
-              } else {
-                const auto m = __builtin_amdgcn_raw_buffer_load_b64(rs_m, off, 0, 0);
-                acc[mt][nt][4 * j + 0] = ((int)(m[0] << 16) > 0) ? acc[mt][nt][4 * j + 0] : 0.0f;
-                acc[mt][nt][4 * j + 1] = ((int)(m[0] & 0xFFFF0000u) > 0) ? acc[mt][nt][4 * j + 1] : 0.0f;
-                acc[mt][nt][4 * j + 2] = ((int)(m[1] << 16) > 0) ? acc[mt][nt][4 * j + 2] : 0.0f;
-                acc[mt][nt][4 * j + 3] = ((int)(m[1] & 0xFFFF0000u) > 0) ? acc[mt][nt][4 * j + 3] : 0.0f;
-              }
-            }
-        }
-        mask_done = true;
-      }
-      using C1 = Cfg<T, C::TH, C::BN, C::WM, C::WN, 1, C::KS, C::NBUF>;
-      static_assert(C1::RING_BYTES <= C::LDS_BYTES, "the 1x1 pass reuses the 3x3 ring");
-      const Phase<T> ph2{static_cast<const T*>(a.x2), static_cast<const T*>(a.w2), a.cin2, false,
-                         sizeof(T) == 2 ? 0x80008000u : 0x80000000u};
-      conv_mainloop<C1>(ph2, geom, smem, acc);
-    }
-  }
-
-  conv_epilogue<C>(a, acc, bias_v, geom, mask_done, smem);
   STV_STAMP(4);
-#endif
-}
-
-// ---- persistent variant: one workgroup per CU walks over several output tiles -----------------------
-// The one-tile kernel pays, per tile, the first DMA round trip (prologue) and the stores (epilogue) with
-// nothing to hide them behind when only one workgroup fits a CU (the 3-deep-ring tiles: 8x128, 8x64).
-// Here the K loop simply continues across tiles: the ring keeps rotating, the DMA of the next tile's first
-// two K-stages is issued during the last two stages of the current tile, and a tile's epilogue (registers
-// -> global) overlaps the other wave's MFMAs of the next tile.  Counted vmcnt waits stay safe next to the
-// epilogue's stores: loads retire in order among themselves, a store in flight can only make
-// "at most PPW operations outstanding" take longer to become true, never true too early.
-// K = 1 group only (KS == 1), no fused second term (stv_conv_igemm_dual keeps the one-tile kernel).
-template <typename C>
-__global__ __launch_bounds__(C::THREADS) void conv_igemm_persistent_kernel(ConvArgs a, int n_workgroups) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  static_assert(C::KS == 1 && C::NBUF == 3, "persistent form: one K group, three-deep ring");
-  using T = typename C::Elem;
-  using FragT = typename Frag<T>::type;
-  using lds_ptr = __attribute__((address_space(3))) void*;
-  constexpr int kVec = elem_traits<T>::kVec;
-  constexpr uint32_t kOob = 0x80000000u;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & (C::NWAVES - 1);
-  const int wm = wave / C::WN, wn = wave % C::WN;
-  const int r = lane & 31, h = lane >> 5;
-
-  const int tiles_x = (a.W + C::TW - 1) / C::TW;
-  const int ntiles = tiles_x * ((a.H + C::TH - 1) / C::TH);
-  const int ny = (a.cout + C::BN - 1) / C::BN;
-  const int total = ntiles * ny;
-  // virtual block b -> (x0, y0, n0), the XCD-aware order of the one-tile kernel (b strides by the grid
-  // size, a multiple of 8: a workgroup's tiles stay on its XCD's side of the mapping)
-  auto decode = [&](int b, int& x0, int& y0, int& n0) {
-    const int round = 8 * ny;
-    const int grp8 = b / round, within = b - grp8 * round;
-    const int left = ntiles - grp8 * 8;
-    const int span = left < 8 ? left : 8;
-    const int tile = grp8 * 8 + within % span;
-    const int yb = within / span;
-    x0 = (tile % tiles_x) * C::TW;
-    y0 = (tile / tiles_x) * C::TH;
-    n0 = yb * C::BN;
-  };
-
-  const T* __restrict__ xin = static_cast<const T*>(a.x);
-  const T* __restrict__ wgt = static_cast<const T*>(a.w);
-  const bool w_blocked = (a.flags & STV_W_BLOCKED) != 0;
-  const int nchunks = a.cin / C::CK;                 // K-stages per tile (>= 2 for every shape this kernel accepts)
-  const uint32_t relu_floor = (a.flags & STV_RELU_IN) ? 0u : (sizeof(T) == 2 ? 0x80008000u : 0x80000000u);
-  const int x_bytes = a.H * a.W * a.cin * (int)sizeof(T);
-  const int w_bytes = C::TAPS * a.cout * a.cin * (int)sizeof(T);
-  const int w_stride = w_blocked ? a.cout * C::KB : C::KB;
-  auto piece_id = [&](int j) { return j * C::NWAVES + wave; };
-
-  // Source offset of DMA piece j = (scalar base of the tile) + (per-lane constant of the kernel).  Input
-  // pieces also carry their halo-tile coordinates (py << 8 | px) for the in-image test of a border tile;
-  // a slot that never holds data (past the halo tile / past the weight rows) is kOob for good.
-  uint32_t rel[C::PPW];
-  int yx[C::PPW];
-#pragma unroll
-  for (int j = 0; j < C::PPW; ++j) {
-    const int g = piece_id(j);
-    if (g < C::IN_PIECES) {
-      const int v = g * 64 + lane;
-      const int pix = v >> 1;
-      const int half = (v & 1) ^ ((pix >> 3) & 1);
-      const int py = pix / C::IN_W, px = pix - py * C::IN_W;
-      rel[j] = pix < C::IN_PIX ? (uint32_t)(((py * a.W + px) * a.cin + half * kVec) * (int)sizeof(T)) : kOob;
-      yx[j] = (py << 8) | px;
-    } else {
-      const int v = (g - C::IN_PIECES) * 64 + lane;
-      const int row = v >> 1;
-      const int half = (v & 1) ^ ((row >> 3) & 1);
-      const int tap = row / C::BN, nn = row - tap * C::BN;
-      const int elem = w_blocked ? ((tap * nchunks * a.cout + nn) * C::CK + half * kVec) : ((tap * a.cout + nn) * a.cin + half * kVec);
-      rel[j] = (row < C::W_ROWS && g < C::PIECES) ? (uint32_t)(elem * (int)sizeof(T)) : kOob;     // (cout % BN == 0: host check)
-      yx[j] = 0;
-    }
-  }
-  auto offset_of = [&](int j, int x0, int y0, int n0) -> uint32_t {
-    const int g = piece_id(j);                               // wave-uniform: the branch is scalar
-    if (rel[j] == kOob) return kOob;
-    if (g < C::IN_PIECES) {
-      const int gy = y0 - C::HALO + (yx[j] >> 8), gx = x0 - C::HALO + (yx[j] & 255);
-      const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-      const int base = ((y0 - C::HALO) * a.W + (x0 - C::HALO)) * a.cin * (int)sizeof(T);
-      return ok ? (uint32_t)(base + (int)rel[j]) : kOob;
-    }
-    return rel[j] + (uint32_t)(n0 * (w_blocked ? C::CK : a.cin) * (int)sizeof(T));
-  };
-  // The accumulators of a tile START at its bias (zero without one): the epilogue has nothing to add and
-  // no bias registers stay live through the K loop.
-  auto init_acc = [&](int n0, f32x16 (&acc)[C::MT][C::NT]) {
-    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.bias), 0, a.bias != nullptr ? a.cout * 4 : 0, 0x00020000);
-#pragma unroll
-    for (int nt = 0; nt < C::NT; ++nt)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int nn = n0 + wn * (C::NT * 32) + nt * 32 + 8 * j + 4 * h;
-        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (uint32_t)(nn * 4), 0, 0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int mt = 0; mt < C::MT; ++mt) acc[mt][nt][4 * j + e] = __uint_as_float(t[e]);
-      }
-  };
-
-  // lane-constant LDS offsets of the fragments (as in conv_mainloop)
-  int a_addr[C::ND][C::AROWS];
-#pragma unroll
-  for (int dx = 0; dx < C::ND; ++dx)
-#pragma unroll
-    for (int j = 0; j < C::AROWS; ++j) {
-      const int pix = (wm * C::MT + j) * C::IN_W + dx + r;
-      a_addr[dx][j] = pix * C::KB + ((h ^ ((pix >> 3) & 1)) << 4);
-    }
-  const int b_lane = C::IN_BYTES + (wn * (C::NT * 32) + r) * C::KB + ((h ^ ((r >> 3) & 1)) << 4);
-  constexpr int NSTEP = C::ND * C::ND;
-  constexpr int PER = (C::PPW + NSTEP - 1) / NSTEP;
-  constexpr int PFB = (C::MT * C::NT >= 4) ? 2 : 3;
-
-  // ---- this workgroup's tiles -----------------------------------------------------------------------
-  const int my_tiles = ((int)blockIdx.x < total) ? (total - 1 - (int)blockIdx.x) / n_workgroups + 1 : 0;
-  if (my_tiles == 0) return;
-  int cx0, cy0, cn0, nx0 = 0, ny0 = 0, nn0 = 0;
-  decode((int)blockIdx.x, cx0, cy0, cn0);
-  bool have_next = my_tiles > 1;
-  if (have_next) decode((int)blockIdx.x + n_workgroups, nx0, ny0, nn0);
-
-  // DMA of piece j of a K-stage: `next` selects the tile, `stage` its K-stage, `live` = there is such a stage
-  auto dma = [&](int j, bool next, int stage, bool live_round, char* buf) {
-    const int g = piece_id(j);
-    const bool in = g < C::IN_PIECES;
-    const bool live = g < C::PIECES && live_round;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<T*>(in ? xin : wgt), 0, live ? (in ? x_bytes : w_bytes) : 0, 0x00020000);
-    char* dst = buf + (g < C::PIECES ? g * 1024 : C::SPARE_OFF);
-    const uint32_t off = next ? offset_of(j, nx0, ny0, nn0) : offset_of(j, cx0, cy0, cn0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)dst, 16, off, stage * (in ? C::KB : w_stride), 0, 0);
-  };
-
-  f32x16 acc[C::MT][C::NT];
-  init_acc(cn0, acc);
-  f32x4 no_bias[C::NT][4];                        // x + (-0) == x: the epilogue's bias add folds away
-#pragma unroll
-  for (int nt = 0; nt < C::NT; ++nt)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) no_bias[nt][j] = f32x4{-0.0f, -0.0f, -0.0f, -0.0f};
-
-  // one K-stage out of `cur` while the stage two ahead (possibly of the next tile) streams into `fill`
-  auto run_stage = [&](const char* cur, char* fill, bool f_next, int f_stage, bool f_live) {
-    FragT af[2][C::AROWS];
-    FragT bf[PFB + 1][C::NT];
-    auto load_a = [&](int dx, int j, int set) {
-      af[set][j] = relu_frag(*reinterpret_cast<const FragT*>(cur + a_addr[dx][j]), relu_floor);
-    };
-    auto load_b = [&](int step) {
-      const int tap = (step % C::ND) * C::ND + step / C::ND;
-#pragma unroll
-      for (int nt = 0; nt < C::NT; ++nt)
-        bf[step % (PFB + 1)][nt] = *reinterpret_cast<const FragT*>(cur + b_lane + (tap * C::BN + nt * 32) * C::KB);
-    };
-    load_b(0);
-#pragma unroll
-    for (int j = 0; j < C::AROWS; ++j) load_a(0, j, 0);
-#pragma unroll
-    for (int q = 1; q < PFB; ++q)
-      if (q < NSTEP) load_b(q);
-#pragma unroll
-    for (int step = 0; step < NSTEP; ++step) {
-      const int dx = step / C::ND, dy = step % C::ND;
-      if (step + PFB < NSTEP) load_b(step + PFB);
-      if (dx + 1 < C::ND) {
-#pragma unroll
-        for (int j = 0; j < C::AROWS; ++j)
-          if ((j < (C::AROWS + 1) / 2 ? 0 : 1) == dy) load_a(dx + 1, j, (dx + 1) & 1);
-      }
-#pragma unroll
-      for (int k = step * PER; k < (step + 1) * PER; ++k)
-        if (k < C::PPW) dma(k, f_next, f_stage, f_live, fill);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int mt = 0; mt < C::MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < C::NT; ++nt) mma<T>(bf[step % (PFB + 1)][nt], af[dx & 1][mt + dy], acc[mt][nt]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    wait_vmcnt<C::PPW>();
-    __builtin_amdgcn_s_barrier();
-  };
-
-  // ---- prologue: K-stages 0 and 1 of the first tile in flight, stage 0 landed ------------------------
-  char* const ring = smem;
-#pragma unroll
-  for (int k = 0; k < C::PPW; ++k) dma(k, false, 0, true, ring);
-#pragma unroll
-  for (int k = 0; k < C::PPW; ++k) dma(k, false, 1, true, ring + C::STAGE_BYTES);
-  wait_vmcnt<C::PPW>();
-  __builtin_amdgcn_s_barrier();
-
-  int slot = 0;                                   // ring buffer of the stage being multiplied
-  for (int t = 0; t < my_tiles; ++t) {
-    for (int s = 0; s < nchunks; ++s) {
-      // the stage two ahead: of this tile, or stage (s + 2 - nchunks) of the next one
-      const bool f_next = s + 2 >= nchunks;
-      const int f_stage = f_next ? s + 2 - nchunks : s + 2;
-      const bool f_live = !f_next || have_next;
-      const int fslot = slot >= 1 ? slot - 1 : 2;          // (slot + 2) % 3
-      run_stage(ring + slot * C::STAGE_BYTES, ring + fslot * C::STAGE_BYTES, f_next, f_stage, f_live);
-      slot = slot == 2 ? 0 : slot + 1;
-    }
-    // ---- tile done: its epilogue, then roll the tile state forward --------------------------------------
-    const Geom geom{a.H, a.W, a.cout, cx0, cy0, cn0, lane, wave, 0, wm, wn, r, h};
-    conv_epilogue<C>(a, acc, no_bias, geom, false, smem);
-    if (t + 1 < my_tiles) {
-      cx0 = nx0; cy0 = ny0; cn0 = nn0;
-      init_acc(cn0, acc);
-      have_next = t + 2 < my_tiles;
-      if (have_next) decode((int)blockIdx.x + (t + 2) * n_workgroups, nx0, ny0, nn0);
-    }
-  }
-  wait_vmcnt<0>();          // the zero-record DMAs of the rounds past the end
 #endif
 }
 
@@ -960,13 +722,10 @@ int launch_cfg(const ConvArgs& a, hipStream_t st) {
 // wave groups, 5 = 8x64 and 6 = 4x64 on a two-deep LDS ring (two / three workgroups per CU),
 // 7 = 2x64 with the K split (the 32x32-pixel layers: four times the workgroups of 4x64 x 2),
 // 8 = 1x64 with the K split in four-wave workgroups (a 32x32-pixel layer then covers all 256 CUs).  -1 = the shape is outside the matrix-core tiling (direct fallback).
-// 9 and 10 = the 8x128 / 8x64 three-deep-ring tiles as PERSISTENT workgroups (conv_igemm_persistent_kernel:
-// one workgroup per CU, the K loop and its DMA ring continue across tiles).
-constexpr int kNumCfg = 11;
-const int kCfgTH[kNumCfg] = {8, 8, 4, 4, 4, 8, 4, 2, 1, 8, 8}, kCfgBN[kNumCfg] = {128, 64, 128, 64, 64, 64, 64, 64, 64, 128, 64};
+constexpr int kNumCfg = 9;
+const int kCfgTH[kNumCfg] = {8, 8, 4, 4, 4, 8, 4, 2, 1}, kCfgBN[kNumCfg] = {128, 64, 128, 64, 64, 64, 64, 64, 64};
 
 bool cfg_valid(int cfg, int cout) { return cfg >= 0 && cfg < kNumCfg && !(cout <= 64 && kCfgBN[cfg] == 128); }
-inline bool cfg_persistent(int cfg) { return cfg == 9 || cfg == 10; }
 
 // Measured choices (stv_conv_tune), keyed by shape.
 struct TuneEntry { int H, W, cin, cout, taps, esize, cfg; };
@@ -1013,24 +772,9 @@ int choose_cfg(int H, int W, int cin, int cout, int elem_bytes, int taps = 9) {
   return t >= 0 ? t : model_cfg(H, W, cin, cout);
 }
 
-template <typename C>
-int launch_persistent(const ConvArgs& a, hipStream_t st) {
-  if (stv_set_max_lds(reinterpret_cast<const void*>(&conv_igemm_persistent_kernel<C>), C::LDS_BYTES) != STV_OK) return STV_ERR_LAUNCH;
-  const int total = ceil_div(a.W, C::TW) * ceil_div(a.H, C::TH) * ceil_div(a.cout, C::BN);
-  int n_wg = stv_device_cus();                   // one workgroup per CU (a multiple of 8: the XCD-aware order holds)
-  if (n_wg > total) n_wg = total;
-  hipLaunchKernelGGL(conv_igemm_persistent_kernel<C>, dim3(n_wg), dim3(C::THREADS), C::LDS_BYTES, st, a, n_wg);
-  STV_CHECK_LAUNCH();
-  return STV_OK;
-}
-
 template <typename T, int TAPS>
 int launch_mfma(const ConvArgs& a, int cfg, hipStream_t st) {
-  // the persistent form has no fused second term and needs at least two K-stages: fall back to its one-tile twin
-  if (cfg_persistent(cfg) && (a.x2 != nullptr || a.cin / (32 / (int)sizeof(T)) < 2 || a.cout % kCfgBN[cfg])) cfg -= 9;
   switch (cfg) {
-    case 9: return launch_persistent<Cfg<T, 8, 128, 4, 2, TAPS>>(a, st);
-    case 10: return launch_persistent<Cfg<T, 8, 64, 4, 2, TAPS>>(a, st);
     // the two 8-row tiles run 8 waves (two per SIMD: one wave's waits hide under the other's MFMAs)
     case 0: return launch_cfg<Cfg<T, 8, 128, 4, 2, TAPS>>(a, st);   // 64 px x 64 couts per wave
     case 1: return launch_cfg<Cfg<T, 8, 64, 4, 2, TAPS>>(a, st);    // 64 px x 32 couts per wave

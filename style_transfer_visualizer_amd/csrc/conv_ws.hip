@@ -378,12 +378,25 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgrou
 #endif
 }
 
+int device_cus() {
+  static std::mutex mu;
+  static int cus[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  std::lock_guard<std::mutex> lk(mu);
+  if (cus[dev] == 0) {
+    hipDeviceProp_t p;
+    cus[dev] = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+  }
+  return cus[dev];
+}
+
 template <bool DG, bool RELU_IN>
 int launch_ws(const ConvArgs& a, hipStream_t st) {
   if (stv_set_max_lds(reinterpret_cast<const void*>(&conv_ws_kernel<DG, RELU_IN>), WsLds<DG>::BYTES) != STV_OK) return STV_ERR_LAUNCH;
   const int ntiles = ceil_div(a.W, TW) * ceil_div(a.H, TH);
   const int ncb = a.cout / 64;
-  int per_cb = stv_device_cus() / ncb;                   // one persistent workgroup per CU
+  int per_cb = device_cus() / ncb;                   // one persistent workgroup per CU
   if (per_cb < 1) per_cb = 1;
   if (per_cb > ntiles) per_cb = ntiles;
   const int n_wg = per_cb * ncb;

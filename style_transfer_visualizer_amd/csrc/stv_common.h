@@ -167,20 +167,6 @@ __device__ __forceinline__ float block_max_256(float v, float* smem4) {
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
-// Compute units of the current device (cached per device); persistent kernels launch one workgroup each.
-inline int stv_device_cus() {
-  static std::mutex mu;
-  static int cus[64];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-  std::lock_guard<std::mutex> lk(mu);
-  if (cus[dev] == 0) {
-    hipDeviceProp_t p;
-    cus[dev] = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
-  }
-  return cus[dev];
-}
-
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device).  Function attributes
 // are per device and callers may launch from several threads / onto several devices, so a plain
 // `static bool` guard is neither thread-safe nor sufficient for a second device.

@@ -131,7 +131,7 @@ def test_conv_igemm_forward(dtype, case, flags, blocked):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [None, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("cfg", [None, 0, 1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("flags", [0, ops.MASK, ops.ACCUM, ops.MASK | ops.ACCUM])
 @pytest.mark.parametrize("case", [(128, 64, 33, 70), (256, 128, 16, 40), (64, 64, 9, 33), (512, 256, 8, 8),
                                   (96, 48, 20, 36)])   # 48 channels: not whole multi-slice stages -> general 1x1 loop
@@ -139,7 +139,7 @@ def test_conv_igemm_dual_dgrad_plus_gram_term(dtype, cfg, flags, case, monkeypat
     """out = [prev +] mask(z>0) * dgrad(dy, w) + F . S^T in one launch: the mask touches the first term only."""
     cd, cs, H, W = case            # channels of the layer above (dy) and of this layer (output, F, S)
     if cfg is not None:
-        if cs <= 64 and cfg in (0, 2, 9):
+        if cs <= 64 and cfg in (0, 2):
             pytest.skip("128-channel tiles need more than 64 output channels")
         monkeypatch.setenv("STV_CONV_CFG", str(cfg))
     w = rnd((cd, cs, 3, 3), 71, -1, 1) * (2.0 / (9 * cd)) ** 0.5
@@ -163,13 +163,13 @@ def test_conv_igemm_dual_dgrad_plus_gram_term(dtype, cfg, flags, case, monkeypat
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [None, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("cfg", [None, 0, 1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("case", [(64, 64, 33, 70), (128, 128, 16, 40), (64, 128, 9, 33), (256, 256, 8, 8)])
 def test_conv_igemm_with_fused_maxpool(dtype, cfg, case, monkeypatch):
     """One launch writes relu(conv) and MaxPool2d(2,2) of it (odd sizes drop the last row / column like torch)."""
     cin, cout, H, W = case
     if cfg is not None:
-        if cout <= 64 and cfg in (0, 2, 9):
+        if cout <= 64 and cfg in (0, 2):
             pytest.skip("128-channel tiles need more than 64 output channels")
         monkeypatch.setenv("STV_CONV_CFG", str(cfg))
     x = rnd((1, cin, H, W), 51)
@@ -256,7 +256,7 @@ def test_conv_ws_forward_pool_and_backward(case, monkeypatch):
         assert_close(ops.from_nhwc(out), xr.grad * (zq > 0).float(), dtype, 9 * 64, f"ws masked dgrad {case}")
 
 
-@pytest.mark.parametrize("cfg", [None, 0, 1, 3, 4, 5, 7, 8, 9, 10])
+@pytest.mark.parametrize("cfg", [None, 0, 1, 3, 4, 5, 7, 8])
 @pytest.mark.parametrize("case", [(128, 64, 32, 64), (256, 128, 16, 40), (512, 512, 8, 8), (512, 256, 12, 20)])
 def test_conv_igemm_route_equals_dgrad_then_pool_backward(cfg, case, monkeypatch):
     """stv_conv_igemm_route: the dgrad of the conv behind a max-pool writes the pre-pool gradient directly.
@@ -265,7 +265,7 @@ def test_conv_igemm_route_equals_dgrad_then_pool_backward(cfg, case, monkeypatch
     cd, cs, H, W = case                      # dy channels (the conv's Cout), routed channels (its Cin), pooled size
     dtype = torch.bfloat16
     if cfg is not None:
-        if cs <= 64 and cfg in (0, 2, 9):
+        if cs <= 64 and cfg in (0, 2):
             pytest.skip("128-channel tiles need more than 64 output channels")
         monkeypatch.setenv("STV_CONV_CFG", str(cfg))
     # a forward conv + pool produces a genuine arg-max map (with ties from the ReLU zeros)
@@ -285,34 +285,6 @@ def test_conv_igemm_route_equals_dgrad_then_pool_backward(cfg, case, monkeypatch
         got = torch.full((2 * H, 2 * W, cs), -3.0, device=DEV, dtype=dtype)
         ops.conv_igemm_route(dy, wb, idx, out=got, flags=flags)
         assert torch.equal(got, want), f"route {case} cfg={cfg} flags={flags}"
-
-
-@pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg,case", [(9, (128, 256, 200, 264)), (10, (128, 64, 232, 300)), (10, (256, 128, 161, 97)), (9, (256, 256, 136, 136))])
-def test_conv_igemm_persistent_many_tiles_per_workgroup(dtype, cfg, case, monkeypatch):
-    """The persistent form of the 8x128 / 8x64 tiles with MORE tiles than CUs (each workgroup walks several
-    tiles: the DMA ring continues across tile boundaries, tiles change their channel block), ragged image
-    edges, bias + ReLU-in + ReLU-out, and the masked / accumulating epilogue of a dgrad."""
-    cin, cout, H, W = case
-    monkeypatch.setenv("STV_CONV_CFG", str(cfg))
-    x = rnd((1, cin, H, W), 171)
-    w = rnd((cout, cin, 3, 3), 172, -1, 1) * (2.0 / (9 * cin)) ** 0.5
-    b = rnd((cout,), 173, -0.2, 0.2)
-    z = rnd((1, cout, H, W), 174)
-    prev = rnd((1, cout, H, W), 175)
-    assert -(-H // 8) * -(-W // 32) * -(-cout // (128 if cfg == 9 else 64)) > 512
-    ref = F.relu(F.conv2d(F.relu(q(x, dtype)), q(w, dtype), b, padding=1))
-    wp = ops.block_weights(ops.pack_weights_fwd(w).to(dtype).to(DEV))
-    y = ops.conv_igemm(ops.to_nhwc(x, dtype).to(DEV), wp, b.to(DEV), flags=ops.RELU_IN | ops.RELU_OUT)
-    assert_close(ops.from_nhwc(y), ref, dtype, 9 * cin, f"persistent cfg {cfg} fwd {case}")
-    ref2 = F.conv2d(q(x, dtype), q(w, dtype), None, padding=1) * (q(z, dtype) > 0).float() + q(prev, dtype)
-    out = ops.to_nhwc(prev, dtype).to(DEV)
-    ops.conv_igemm(ops.to_nhwc(x, dtype).to(DEV), wp, None, ref=ops.to_nhwc(z, dtype).to(DEV), out=out, flags=ops.MASK | ops.ACCUM)
-    assert_close(ops.from_nhwc(out), ref2, dtype, 9 * cin, f"persistent cfg {cfg} mask+accum {case}")
-    if H % 2 == 0 and W % 2 == 0:
-        idx = torch.full((H // 2, W // 2, cout), 255, device=DEV, dtype=torch.uint8)
-        y2, yp = ops.conv_igemm_pool(ops.to_nhwc(x, dtype).to(DEV), wp, b.to(DEV), flags=ops.RELU_OUT, pool_idx=idx)
-        assert torch.equal(ops.from_nhwc(yp).cpu(), F.max_pool2d(ops.from_nhwc(y2).cpu(), 2, 2))
 
 
 def test_conv_ws_matches_the_general_kernel(monkeypatch):
@@ -341,12 +313,12 @@ def test_conv_ws_matches_the_general_kernel(monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("case", [(128, 128, 21, 70), (64, 64, 9, 33), (48, 136, 12, 40), (512, 128, 8, 8)])
 def test_conv_igemm_every_tile_config(dtype, cfg, case, monkeypatch):
     """Each tile shape / wave layout / K split (forced with STV_CONV_CFG) on full, ragged and odd-K shapes."""
     cin, cout, H, W = case
-    if cout <= 64 and cfg in (0, 2, 9):
+    if cout <= 64 and cfg in (0, 2):
         pytest.skip("128-channel tiles need more than 64 output channels")
     monkeypatch.setenv("STV_CONV_CFG", str(cfg))
     x = rnd((1, cin, H, W), 41)
