@@ -547,7 +547,10 @@ extern "C" int stv_gram_ksplit(int n_pixels, int channels) {
   static const int wg_max = getenv("STV_GRAM_WGS") ? atoi(getenv("STV_GRAM_WGS")) : 512;     // tuning aid
   static const int wg_min = getenv("STV_GRAM_WGS_MIN") ? atoi(getenv("STV_GRAM_WGS_MIN")) : 128;
   const int lo = ceil_div(wg_min, pairs), hi = (wg_max / pairs) > 0 ? wg_max / pairs : 1;
-  static const int kdiv = getenv("STV_GRAM_KDIV") ? atoi(getenv("STV_GRAM_KDIV")) : 2;
+  // pixels per slab >= kdiv * channels: the fp32 slabs are written once and re-read once by the finish
+  // kernel - at 2 they added up to as much traffic as the feature maps themselves (206 MB at 1024^2);
+  // round-2 sweep (bench.py closure, MI355X): 8 is the knee (Gram chain 108 -> 90 us at 1024^2, 48 -> 44 at 512^2)
+  static const int kdiv = getenv("STV_GRAM_KDIV") ? atoi(getenv("STV_GRAM_KDIV")) : 8;
   int ks = n_pixels / (kdiv * channels);
   if (ks < lo) ks = lo;
   if (ks > hi) ks = hi;
