@@ -56,9 +56,8 @@ def conv_flops(meta) -> float:
     return flops
 
 
-_CFG_NAMES = {0: "8, 128, 4, 2", 1: "8, 64, 4, 2", 2: "4, 128, 1, 4", 3: "4, 64, 2, 2", 4: "4, 64, 2, 2", 5: "8, 64, 4, 2", 6: "4, 64, 2, 2", 7: "2, 64, 2, 2", 8: "1, 64, 1, 2",
-              9: "4, 64, 2, 2", 10: "8, 64, 4, 2", 11: "8, 64, 4, 2", 12: "4, 64, 2, 2"}
-_CFG_KS = {0: "1, 3", 1: "1, 3", 2: "1, 3", 3: "1, 3", 4: "2, 3", 5: "1, 2", 6: "1, 2", 7: "2, 3", 8: "2, 3", 9: "2, 3", 10: "1, 3", 11: "1, 2", 12: "1, 3"}
+_CFG_NAMES = {0: "8, 128, 4, 2", 1: "8, 64, 4, 2", 2: "4, 128, 1, 4", 3: "4, 64, 2, 2", 4: "4, 64, 2, 2", 5: "8, 64, 4, 2", 6: "4, 64, 2, 2", 7: "2, 64, 2, 2", 8: "1, 64, 1, 2"}
+_CFG_KS = {0: "1, 3", 1: "1, 3", 2: "1, 3", 3: "1, 3", 4: "2, 3", 5: "1, 2", 6: "1, 2", 7: "2, 3", 8: "2, 3"}
 
 
 def kernel_group(meta, OP, dtype_code: int = 1) -> str | None:
@@ -72,10 +71,7 @@ def kernel_group(meta, OP, dtype_code: int = 1) -> str | None:
         elem = "unsigned short" if dtype_code == 1 else "float"
         if cfg < 0:
             return f"conv_direct_kernel<{elem}, {taps}>"
-        if taps != 9 and cfg >= 9:
-            cfg = {9: 4, 10: 1, 11: 5, 12: 3}[cfg]                  # a 1x1 runs the tile without column reuse
-        kind = "CfgAR" if cfg >= 9 else "Cfg"                        # CfgAR: A-column reuse (fewer LDS reads)
-        return f"conv_igemm_kernel<{kind}<{elem}, {_CFG_NAMES[cfg]}, {taps}, {_CFG_KS[cfg]}>>"
+        return f"conv_igemm_kernel<Cfg<{elem}, {_CFG_NAMES[cfg]}, {taps}, {_CFG_KS[cfg]}>>"
     names = {OP["CONV_FIRST_FWD"]: "conv_first_fwd", OP["CONV_FIRST_DGRAD"]: "conv_first_dgrad",
              OP["POOL_FWD"]: "maxpool_fwd", OP["POOL_BWD"]: "maxpool_bwd", OP["GRAM_PARTIAL"]: "gram_partial",
              OP["GRAM_FINISH"]: "gram_finish", OP["GRAM_MULTI"]: "gram_multi (batched partial + finish)", OP["CONTENT_LOSS"]: "content_loss",

@@ -108,19 +108,6 @@ struct Cfg {
   static_assert(TH % WM == 0 && BN % (WN * 32) == 0, "tile split");
   static_assert(BN % 16 == 0, "swizzle period");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-  // AR: the A fragments of the middle tap column are not read from LDS but built from the two outer
-  // columns' registers with one-lane wave shifts (CfgAR below)
-  static constexpr bool AR = false;
-};
-// Same tile with "A-column reuse".  Per K-stage a wave reads 3 (MT+2) A fragments: the halo rows for
-// dx = 0, 1, 2 - the same 34 pixels of a row, shifted by one lane.  The small tiles (MT = 2, NT = 1) need
-// 149 B/clk of LDS reads per CU at full MFMA rate against the 128 B/clk the LDS delivers;
-// here column 1 comes from column 0 shifted one lane down the wave (v_mov_dpp wave_shl:1; lane 31 of each
-// half takes pixel 32 from column 2 shifted the other way): 2 (MT+2) LDS reads + 12 VALU per row.
-template <typename T, int TH_, int BN_, int WM_, int WN_, int TAPS_, int KS_ = 1, int NBUF_ = 3>
-struct CfgAR : Cfg<T, TH_, BN_, WM_, WN_, TAPS_, KS_, NBUF_> {
-  static constexpr bool AR = true;
-  static_assert(TAPS_ == 9, "column reuse is a 3x3 notion");
 };
 
 template <typename T> struct Frag;
@@ -256,59 +243,8 @@ __device__ __forceinline__ void conv_mainloop(const Phase<typename C::Elem>& ph,
   // three dy, so a stage reads 3*(MT+2) A fragments instead of 9*MT.  Fragments are fetched ahead
   // of the MFMAs that use them.
   auto run_stage = [&](const char* cur, char* fill, int l) {
-    FragT bf[PFB + 1][C::NT];
-    if constexpr (C::AR) {
-      FragT fa[3][C::AROWS];            // halo rows as seen by the three tap columns
-      auto load_b = [&](int step) {
-        const int tap = (step % C::ND) * C::ND + step / C::ND;     // dy * 3 + dx
-#pragma unroll
-        for (int nt = 0; nt < C::NT; ++nt)
-          bf[step % (PFB + 1)][nt] = *reinterpret_cast<const FragT*>(cur + b_lane + (tap * C::BN + nt * 32) * C::KB);
-      };
-      auto middle = [&](int j) {        // column 1 of row j: pixel r + 1 = column 0 of lane r + 1; lane 31: pixel 32 = column 2 of lane 30
-        typedef __attribute__((ext_vector_type(4))) int i32x4;
-        const i32x4 lo = __builtin_bit_cast(i32x4, fa[0][j]), hi = __builtin_bit_cast(i32x4, fa[2][j]);
-        i32x4 o;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          const int down = __builtin_amdgcn_update_dpp(0, lo[d], 0x130, 0xF, 0xF, true);   // wave_shl:1: lane <- lane + 1
-          const int up = __builtin_amdgcn_update_dpp(0, hi[d], 0x138, 0xF, 0xF, true);     // wave_shr:1: lane <- lane - 1
-          o[d] = (r == 31) ? up : down;
-        }
-        fa[1][j] = __builtin_bit_cast(FragT, o);
-      };
-      load_b(0);
-#pragma unroll
-      for (int j = 0; j < C::AROWS; ++j) fa[0][j] = relu_frag(*reinterpret_cast<const FragT*>(cur + a_addr[0][j]), ph.relu_floor);
-#pragma unroll
-      for (int j = 0; j < C::AROWS; ++j) fa[2][j] = relu_frag(*reinterpret_cast<const FragT*>(cur + a_addr[2][j]), ph.relu_floor);
-#pragma unroll
-      for (int q = 1; q < PFB; ++q)
-        if (q < NSTEP) load_b(q);
-#pragma unroll
-      for (int step = 0; step < NSTEP; ++step) {
-        const int dx = step / C::ND, dy = step % C::ND;
-        if (step + PFB < NSTEP) load_b(step + PFB);
-        if (dx == 0) {                  // build column 1 in the shadow of column 0's MFMAs
-#pragma unroll
-          for (int j = 0; j < C::AROWS; ++j)
-            if ((j < (C::AROWS + 1) / 2 ? 0 : 1) == dy) middle(j);
-        }
-#pragma unroll
-        for (int k = step * PER; k < (step + 1) * PER; ++k)
-          if (k < C::PPW) dma(k, l + C::NBUF - 1, fill);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int mt = 0; mt < C::MT; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < C::NT; ++nt) mma<T>(bf[step % (PFB + 1)][nt], fa[dx][mt + dy], acc[mt][nt]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      wait_vmcnt<(C::NBUF - 2) * C::PPW>();
-      __builtin_amdgcn_s_barrier();
-      return;
-    }
     FragT af[2][C::AROWS];
+    FragT bf[PFB + 1][C::NT];
     auto load_a = [&](int dx, int j, int set) {
       af[set][j] = relu_frag(*reinterpret_cast<const FragT*>(cur + a_addr[dx][j]), ph.relu_floor);
     };
@@ -786,10 +722,8 @@ int launch_cfg(const ConvArgs& a, hipStream_t st) {
 // wave groups, 5 = 8x64 and 6 = 4x64 on a two-deep LDS ring (two / three workgroups per CU),
 // 7 = 2x64 with the K split (the 32x32-pixel layers: four times the workgroups of 4x64 x 2),
 // 8 = 1x64 with the K split in four-wave workgroups (a 32x32-pixel layer then covers all 256 CUs).  -1 = the shape is outside the matrix-core tiling (direct fallback).
-// 9..12 = the tiles 4, 1, 5, 3 with A-column reuse (CfgAR: the middle tap column from registers, fewer LDS reads).
-constexpr int kNumCfg = 13;
-const int kCfgTH[kNumCfg] = {8, 8, 4, 4, 4, 8, 4, 2, 1, 4, 8, 8, 4}, kCfgBN[kNumCfg] = {128, 64, 128, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64};
-const int kCfgBase[kNumCfg] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 4, 1, 5, 3};     // the same tile without column reuse
+constexpr int kNumCfg = 9;
+const int kCfgTH[kNumCfg] = {8, 8, 4, 4, 4, 8, 4, 2, 1}, kCfgBN[kNumCfg] = {128, 64, 128, 64, 64, 64, 64, 64, 64};
 
 bool cfg_valid(int cfg, int cout) { return cfg >= 0 && cfg < kNumCfg && !(cout <= 64 && kCfgBN[cfg] == 128); }
 
@@ -840,16 +774,6 @@ int choose_cfg(int H, int W, int cin, int cout, int elem_bytes, int taps = 9) {
 
 template <typename T, int TAPS>
 int launch_mfma(const ConvArgs& a, int cfg, hipStream_t st) {
-  if (TAPS != 9 && cfg >= 9 && cfg < kNumCfg) cfg = kCfgBase[cfg];      // a 1x1 has no tap columns to share
-  if constexpr (TAPS == 9) {
-    switch (cfg) {
-      case 9: return launch_cfg<CfgAR<T, 4, 64, 2, 2, TAPS, 2>>(a, st);
-      case 10: return launch_cfg<CfgAR<T, 8, 64, 4, 2, TAPS>>(a, st);
-      case 11: return launch_cfg<CfgAR<T, 8, 64, 4, 2, TAPS, 1, 2>>(a, st);
-      case 12: return launch_cfg<CfgAR<T, 4, 64, 2, 2, TAPS>>(a, st);
-      default: break;
-    }
-  }
   switch (cfg) {
     // the two 8-row tiles run 8 waves (two per SIMD: one wave's waits hide under the other's MFMAs)
     case 0: return launch_cfg<Cfg<T, 8, 128, 4, 2, TAPS>>(a, st);   // 64 px x 64 couts per wave
