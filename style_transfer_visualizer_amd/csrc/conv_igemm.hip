@@ -161,7 +161,11 @@ struct Geom {
   int lane, wave, grp, wm, wn, r, h;
 };
 
-template <typename C>
+// RELU: the input passes through a ReLU while it is read (STV_RELU_IN).  A compile-time switch, not a
+// scalar floor: the packed max costs four VALU per A fragment (48-72 per K-stage) and the tiles are
+// sensitive to exactly that (round-2 A/B: 12 extra VALU per halo row made them 2-18 % slower), while
+// only the forward convs behind a tapped (pre-ReLU) layer need it - none of the dgrads do.
+template <typename C, bool RELU>
 __device__ __forceinline__ void conv_mainloop(const Phase<typename C::Elem>& ph, const Geom& gm, char* smem,
                                               f32x16 (&acc)[C::MT][C::NT]) {
   using T = typename C::Elem;
@@ -246,7 +250,8 @@ __device__ __forceinline__ void conv_mainloop(const Phase<typename C::Elem>& ph,
     FragT af[2][C::AROWS];
     FragT bf[PFB + 1][C::NT];
     auto load_a = [&](int dx, int j, int set) {
-      af[set][j] = relu_frag(*reinterpret_cast<const FragT*>(cur + a_addr[dx][j]), ph.relu_floor);
+      const FragT v = *reinterpret_cast<const FragT*>(cur + a_addr[dx][j]);
+      af[set][j] = RELU ? relu_frag(v, 0u) : v;
     };
     auto load_b = [&](int step) {
       const int tap = (step % C::ND) * C::ND + step / C::ND;     // dy * 3 + dx
@@ -323,7 +328,7 @@ __device__ __forceinline__ void conv_mainloop(const Phase<typename C::Elem>& ph,
 
 }
 
-template <typename C>
+template <typename C, bool RELU>
 __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (LDS address-space casts are device-only)
   using T = typename C::Elem;
@@ -393,7 +398,7 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
   constexpr uint32_t kOob = 0x80000000u;   // >= num_records for every tensor this kernel accepts
   const Geom geom{a.H, a.W, a.cout, x0, y0, n0, lane, wave, grp, wm, wn, r, h};
   const Phase<T> ph1{xin, wgt, a.cin, w_blocked, relu_floor};
-  conv_mainloop<C>(ph1, geom, smem, acc);
+  conv_mainloop<C, RELU>(ph1, geom, smem, acc);
   STV_STAMP(2);
 
   // ---- fused second term (3x3 kernels only): the ReLU mask belongs to the first term alone, so it
@@ -435,7 +440,7 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
       static_assert(C1::RING_BYTES <= C::LDS_BYTES, "the 1x1 pass reuses the 3x3 ring");
       const Phase<T> ph2{static_cast<const T*>(a.x2), static_cast<const T*>(a.w2), a.cin2, false,
                          sizeof(T) == 2 ? 0x80008000u : 0x80000000u};
-      conv_mainloop<C1>(ph2, geom, smem, acc);
+      conv_mainloop<C1, false>(ph2, geom, smem, acc);
     }
   }
 
@@ -709,10 +714,14 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs a) {
 
 template <typename C>
 int launch_cfg(const ConvArgs& a, hipStream_t st) {
-  if (stv_set_max_lds(reinterpret_cast<const void*>(&conv_igemm_kernel<C>), C::LDS_BYTES) != STV_OK) return STV_ERR_LAUNCH;
+  const bool relu = (a.flags & STV_RELU_IN) != 0;
+  const void* fn = relu ? reinterpret_cast<const void*>(&conv_igemm_kernel<C, true>)
+                        : reinterpret_cast<const void*>(&conv_igemm_kernel<C, false>);
+  if (stv_set_max_lds(fn, C::LDS_BYTES) != STV_OK) return STV_ERR_LAUNCH;
   const int tiles = ceil_div(a.W, C::TW) * ceil_div(a.H, C::TH);
   dim3 grid(tiles * ceil_div(a.cout, C::BN));      // decoded XCD-aware in the kernel
-  hipLaunchKernelGGL(conv_igemm_kernel<C>, grid, dim3(C::THREADS), C::LDS_BYTES, st, a);
+  if (relu) hipLaunchKernelGGL((conv_igemm_kernel<C, true>), grid, dim3(C::THREADS), C::LDS_BYTES, st, a);
+  else hipLaunchKernelGGL((conv_igemm_kernel<C, false>), grid, dim3(C::THREADS), C::LDS_BYTES, st, a);
   STV_CHECK_LAUNCH();
   return STV_OK;
 }
