@@ -60,7 +60,7 @@ _CFG_NAMES = {0: "8, 128, 4, 2", 1: "8, 64, 4, 2", 2: "4, 128, 1, 4", 3: "4, 64,
 _CFG_KS = {0: "1, 3", 1: "1, 3", 2: "1, 3", 3: "1, 3", 4: "2, 3", 5: "1, 2", 6: "1, 2", 7: "2, 3", 8: "2, 3"}
 
 
-def kernel_group(meta, OP, dtype_code: int = 1) -> str | None:
+def kernel_group(meta, OP, dtype_code: int = 1, flags: int = 0) -> str | None:
     """Kernel (template instantiation) an op runs as - the names rocprofv3 --kernel-trace reports."""
     from style_transfer_visualizer_amd import _lib
     op, H, W, cin, cout, taps, _n = meta
@@ -71,7 +71,8 @@ def kernel_group(meta, OP, dtype_code: int = 1) -> str | None:
         elem = "unsigned short" if dtype_code == 1 else "float"
         if cfg < 0:
             return f"conv_direct_kernel<{elem}, {taps}>"
-        return f"conv_igemm_kernel<Cfg<{elem}, {_CFG_NAMES[cfg]}, {taps}, {_CFG_KS[cfg]}>>"
+        relu = "true" if (flags & 1) else "false"                  # STV_RELU_IN: the ReLU-on-load instantiation
+        return f"conv_igemm_kernel<Cfg<{elem}, {_CFG_NAMES[cfg]}, {taps}, {_CFG_KS[cfg]}>, {relu}>"
     names = {OP["CONV_FIRST_FWD"]: "conv_first_fwd", OP["CONV_FIRST_DGRAD"]: "conv_first_dgrad",
              OP["POOL_FWD"]: "maxpool_fwd", OP["POOL_BWD"]: "maxpool_bwd", OP["GRAM_PARTIAL"]: "gram_partial",
              OP["GRAM_FINISH"]: "gram_finish", OP["GRAM_MULTI"]: "gram_multi (batched partial + finish)", OP["CONTENT_LOSS"]: "content_loss",
@@ -96,7 +97,8 @@ def pmc_traffic(kernel: str, size: int) -> tuple[int | None, str | None]:
         if m is None:
             m2 = re.search(r"(conv_ws_kernel<\w+)", name)       # conv_ws_kernel<DG, RELU_IN>: keyed by its first flag
             return re.sub(r"\s+", "", m2.group(1)) if m2 else re.sub(r"\s+", "", name)
-        return re.sub(r"\s+", "", m.group(1) + "|" + m.group(2))
+        inst = re.search(r">\s*,\s*(true|false)\s*>", name)                # conv_igemm_kernel<Cfg<...>, RELU>
+        return re.sub(r"\s+", "", m.group(1) + "|" + m.group(2) + ("|" + inst.group(1) if inst else ""))
     try:
         data = json.load(open(path))["kernels"]
     except (OSError, ValueError, KeyError):
@@ -212,8 +214,8 @@ def run_gpu(args, rank: int, world: int, device: torch.device, size: int, steps:
             passes = [prog.profile(reps=8) for _ in range(3)]
         ms = [sum(p[i] for p in passes) / len(passes) for i in range(prog.n_ops)]
         groups: dict = {}
-        for meta, t in zip(prog.op_meta, ms, strict=True):
-            g = kernel_group(meta, OP, 1 if precision == "bf16" else 0)
+        for meta, fl, t in zip(prog.op_meta, prog.op_flags, ms, strict=True):
+            g = kernel_group(meta, OP, 1 if precision == "bf16" else 0, fl)
             e = groups.setdefault(g, {"ms": 0.0, "flops": 0.0, "launches": 0})
             e["ms"] += t
             e["launches"] += 1

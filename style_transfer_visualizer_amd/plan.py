@@ -419,6 +419,7 @@ class Program:
         self.n_ops = len(op_list)
         self.op_meta = [(int(o.op), int(o.H), int(o.W), int(o.cin), int(o.cout), int(o.taps), int(o.n))
                         for o in op_list]
+        self.op_flags = [int(o.flags) for o in op_list]
 
     def run(self, use_graph: bool = False) -> None:
         lib = _lib.load()
