@@ -108,6 +108,10 @@ def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # Load order matters: PyTorch ships its own libamdhip64; if this library pulled in the system copy
+    # first, the process would hold two HIP runtimes and every pointer / stream handed over from torch
+    # would be foreign to the kernels here (seen as STV_ERR_LAUNCH on the first call).
+    import torch  # noqa: F401, PLC0415
     if not os.path.exists(LIB_PATH):
         msg = (f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                "(hipcc --offload-arch=gfx950). There is no CPU/eager fallback for this path.")
