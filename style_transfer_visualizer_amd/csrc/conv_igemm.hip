@@ -949,7 +949,8 @@ extern "C" int stv_conv_igemm_route(const void* x, const void* w, const void* po
   if (!x || !w || !pool_idx || !y_full || H <= 0 || W <= 0 || cin <= 0 || cout <= 0) return STV_ERR_ARG;
   if (dtype != STV_BF16) return STV_ERR_ARG;                                   // packed-word routing: bf16 storage only
   if (flags & (STV_RELU_IN | STV_RELU_OUT | STV_ACCUM)) return STV_ERR_ARG;
-  if ((size_t)4 * H * W * (size_t)(cin > cout ? cin : cout) * 2 >= (size_t)1 << 31) return STV_ERR_ARG;
+  // 32-bit buffer offsets: the input (H x W x cin) and the routed output (2H x 2W x cout), bf16
+  if ((size_t)H * W * (size_t)cin * 2 >= (size_t)1 << 31 || (size_t)4 * H * W * (size_t)cout * 2 >= (size_t)1 << 31) return STV_ERR_ARG;
   if (choose_cfg(H, W, cin, cout, 2, 9) < 0) return STV_ERR_ARG;
   ConvArgs a{x, w, nullptr, nullptr, y_full, H, W, cin, cout, flags, nullptr, nullptr, nullptr, nullptr, 0};
   a.route_idx = pool_idx;

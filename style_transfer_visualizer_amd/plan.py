@@ -372,7 +372,8 @@ class Schedule:
                         and self.dtype == torch.bfloat16 and nd.wb.dim() == 4 and not s.taps and not mask_src
                         and id(s) not in written and pool_nd.src.H == 2 * s.H and pool_nd.src.W == 2 * s.W
                         and id(pool_nd.src) not in written
-                        and 4 * s.act.numel() * s.act.element_size() < 2 ** 31):
+                        and 4 * s.act.numel() * s.act.element_size() < 2 ** 31
+                        and d.grad.numel() * d.grad.element_size() < 2 ** 31):
                     ps = pool_nd.src
                     rflags = (MASK if (ps.relu_fused and not ps.taps) else 0) | W_BLOCKED | POOL_ROUTE
                     out.append(self._op(op=OP_CONV, p0=d.grad, p1=nd.wb, p2=pool_nd.idx, q1=ps.grad, H=s.H, W=s.W,
