@@ -23,10 +23,10 @@ for (H, cout, relu, pool) in ((1024, 64, True, True), (512, 128, False, False), 
     else:
         us = t(lambda: ops.conv_igemm(x, w, b, out=y, flags=fl))
     gf = 2 * 9 * 64 * cout * H * H / 1e9
-    print(f"diag={os.environ.get('STV_WS_DIAG','0')} fwd {H}^2 64->{cout} relu={relu} pool={pool}: {us:7.1f} us  {gf / us / 1e3:7.1f} TF/s")
+    print(f"diag={os.environ.get('STV_WS_DIAG','0')} fwd {H}^2 64->{cout} relu={relu} pool={pool}: {us:7.1f} us  {gf / us * 1e3:7.0f} TFLOP/s")
 H = 1024
 dy = (torch.randn(H, H, 64, device=dev) * 0.5).bfloat16(); z = (torch.randn(H, H, 64, device=dev)).bfloat16()
 wb = ops.block_weights((torch.randn(9, 64, 64, device=dev) * 0.06).bfloat16()); S = (torch.randn(64, 64, device=dev) * 0.01).bfloat16()
 out = torch.empty(H, H, 64, device=dev, dtype=torch.bfloat16)
 us = t(lambda: ops.conv_igemm_dual(dy, wb, z, S, ref=z, out=out, flags=ops.MASK))
-print(f"diag={os.environ.get('STV_WS_DIAG','0')} dgrad+mask+gram 1024^2 64->64: {us:7.1f} us  {2*(9*64+64)*64*H*H/1e9/us/1e3:7.1f} TF/s")
+print(f"diag={os.environ.get('STV_WS_DIAG','0')} dgrad+mask+gram 1024^2 64->64: {us:7.1f} us  {2*(9*64+64)*64*H*H/1e9/us*1e3:7.0f} TFLOP/s")
