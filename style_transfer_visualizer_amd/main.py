@@ -55,3 +55,24 @@ def style_transfer(paths: InputPaths, config, *, video_writer=None, gif_collecto
         video_created=video_writer is not None, gif_created=gif_collector is not None,
         plot_losses=config.output.plot_losses))
     return input_img.detach().clamp(0, 1)
+
+
+def style_transfer_batch(pairs: list[InputPaths], config) -> list[torch.Tensor]:
+    """Several INDEPENDENT content/style pairs, one process per GPU (launch with torchrun).
+
+    Not a tensor batch - ``gram_matrix`` folds a batch dimension into channels (reference
+    core_model.py:56-57) - but N replicas of the single-image path: rank r runs pairs r, r + world, ...
+    each with its own model targets and L-BFGS state, writes their PNGs, and one all-gather at the end
+    hands every rank the full ordered list of result images (they must share one size).
+    """
+    import copy  # noqa: PLC0415
+
+    from . import parallel  # noqa: PLC0415
+
+    _rank, local_rank, _world = parallel.init_distributed()
+    if torch.cuda.is_available():              # "cuda" in the config then means this rank's GPU
+        torch.cuda.set_device(local_rank % torch.cuda.device_count())
+
+    def one(_index: int, paths: InputPaths) -> torch.Tensor:
+        return style_transfer(paths, copy.deepcopy(config)).contiguous()
+    return parallel.run_sharded(list(pairs), one)

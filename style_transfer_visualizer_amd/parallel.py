@@ -85,3 +85,16 @@ def gather_results(local: list[tuple[int, torch.Tensor]], n_items: int) -> list[
             if idx >= 0:
                 out[idx] = imgs[k]
     return out
+
+
+def run_sharded(items: list, fn, *, backend: str | None = None) -> list:
+    """Run ``fn(index, item) -> Tensor`` on this rank's share of ``items`` (round-robin) and return the
+    results of ALL items, in order, on every rank (one all-gather at the end; no collective in between).
+
+    This is BASELINE configs[3]'s pattern - N independent content/style pairs, one per GPU - as a library
+    call: ``main.style_transfer_batch`` and ``bench.py --gpus N`` are thin callers.  Works without a
+    process group too (one process runs every item).
+    """
+    rank, _local, world = init_distributed(backend)
+    local = [(i, fn(i, items[i])) for i in shard_items(len(items), rank, world)]
+    return gather_results(local, len(items))

@@ -26,9 +26,16 @@ def _worker(rank: int, world: int, port: int, n_items: int, out_q) -> None:
     # stand-in for the per-image optimisation: a deterministic function of the item index
     local = [(i, torch.full((1, 3, 4, 4), float(i) + 0.5)) for i in mine]
     full = parallel.gather_results(local, n_items)
-    out_q.put((rank, mine, [float(t.mean()) for t in full]))
-    dist.barrier()
-    dist.destroy_process_group()
+    # the same through the library entry point main.style_transfer_batch / bench.py build on
+    ran = []
+
+    def fn(i, item):
+        ran.append(i)
+        return torch.full((1, 3, 4, 4), float(item) * 2.0)
+    again = parallel.run_sharded([10.0 * k for k in range(n_items)], fn, backend="gloo")
+    assert ran == mine
+    out_q.put((rank, mine, [float(t.mean()) for t in full], [float(t.mean()) for t in again]))
+    parallel.shutdown()
 
 
 def test_two_ranks_shard_and_gather():
@@ -43,13 +50,16 @@ def test_two_ranks_shard_and_gather():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    by_rank = {r: (mine, vals) for r, mine, vals in results}
+    by_rank = {r: (mine, vals, again) for r, mine, vals, again in results}
     assert by_rank[0][0] == [0, 2, 4] and by_rank[1][0] == [1, 3]
     expected = [i + 0.5 for i in range(n_items)]
     assert by_rank[0][1] == expected and by_rank[1][1] == expected      # every rank holds the ordered full set
+    assert by_rank[0][2] == by_rank[1][2] == [20.0 * k for k in range(n_items)]
 
 
 def test_single_process_paths():
     assert parallel.shard_items(5, 0, 1) == [0, 1, 2, 3, 4]
     out = parallel.gather_results([(1, torch.ones(2)), (0, torch.zeros(2))], 2)
     assert torch.equal(out[0], torch.zeros(2)) and torch.equal(out[1], torch.ones(2))
+    res = parallel.run_sharded(["a", "bb", "ccc"], lambda i, item: torch.tensor([float(len(item) + i)]))
+    assert [float(t) for t in res] == [1.0, 3.0, 5.0]
