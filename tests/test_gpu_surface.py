@@ -237,3 +237,28 @@ def test_input_channel_count_and_stale_backward_are_rejected(monkeypatch):
         model(xt.clone())                      # fresh non-contiguous temporary each time
         model(xt.double())
     assert len(eng._programs) == n_prog
+
+
+def test_style_transfer_batch_runs_independent_pairs(tmp_path, monkeypatch):
+    """main.style_transfer_batch (BASELINE configs[3] as a library call; one process here, ranks under
+    torchrun): every pair gets its own targets and optimizer state and its own PNG; results come back in order."""
+    from PIL import Image
+
+    from style_transfer_visualizer_amd import main as stv_main
+    from style_transfer_visualizer_amd.type_defs import InputPaths
+    monkeypatch.setenv("STV_SYNTHETIC_WEIGHTS", "0")
+    for name, seed in (("c0", 0), ("c1", 3), ("s", 1)):
+        img = synthetic.synthetic_image(seed, 64, 64, normalize=False)[0].permute(1, 2, 0).mul(255).byte().numpy()
+        Image.fromarray(img).save(tmp_path / f"{name}.png")
+    cfg = stv_config.StyleTransferConfig.model_validate({})
+    cfg.optimization.steps, cfg.optimization.init_method = 4, "random"
+    cfg.video.create_video, cfg.video.final_only = False, True
+    cfg.output.output = str(tmp_path / "out")
+    cfg.hardware.device = "cuda"
+    pairs = [InputPaths(content_path=str(tmp_path / "c0.png"), style_path=str(tmp_path / "s.png")),
+             InputPaths(content_path=str(tmp_path / "c1.png"), style_path=str(tmp_path / "s.png"))]
+    out = stv_main.style_transfer_batch(pairs, cfg)
+    assert len(out) == 2 and all(t.shape == (1, 3, 64, 64) for t in out)
+    assert all(float(t.min()) >= 0.0 and float(t.max()) <= 1.0 for t in out)
+    assert not torch.equal(out[0], out[1])
+    assert (tmp_path / "out" / "stylized_c0_x_s.png").is_file() and (tmp_path / "out" / "stylized_c1_x_s.png").is_file()
