@@ -389,27 +389,33 @@ __global__ __launch_bounds__(256) void conv_first_fwd_mfma(const float* __restri
 }
 
 // ---- input gradient on the matrix cores (bf16 activations) -----------------------------------------
-// dx[c][p] = sum_tap sum_n dy[p + off(tap)][n] * wd[tap][c][n]: M = pixels, N = 3 (padded to the 16
-// columns of v_mfma_f32_16x16x32_bf16), K = 9 x 64.  dy is bf16 as stored; the weights are split in
-// two bf16 terms so the product stays fp32-faithful.  Only 12 lanes of a weight fragment are
-// non-zero (3 channels x 4 k-groups), so the fragment table is 7 KB of LDS.
+// dx[c][p] = sum_tap sum_n dy[p + off(tap)][n] * wd[tap][c][n]: M = pixels, K = 64 channels per tap, N = 3.
+// The three HORIZONTAL taps of a kernel row ride in the 16 columns of v_mfma_f32_16x16x32_bf16 next to the
+// three channels: column 4 dxo + c.  One A fragment (16 pixels x 32 channels of a dy row) then serves all
+// three horizontal taps at once - a third of the MFMAs and of the LDS reads of a tap-by-tap product
+// (9 x 2 x 2 MFMAs per 16 pixels, 13 of 16 columns idle) - and what comes out is D[p'][dxo, c], the
+// contribution of input pixel p' to output pixel p' - dxo: a shifted three-term sum finishes the job through
+// a 6-KB per-wave LDS patch.  dy is bf16 as stored; the weights are split in two bf16 terms so the product
+// stays fp32-faithful.  36 lanes of a weight fragment are non-zero (9 columns x 4 k-groups): a 7 KB table.
 #ifndef STV_DG_TH
 #define STV_DG_TH 8
 #endif
 constexpr int DG_TH = STV_DG_TH, DG_TW = 32, DG_IW = DG_TW + 2, DG_PITCH = 128 + 16;
 constexpr int DG_RW = DG_TH / 4;                            // output rows per wave
-constexpr int DG_MB = DG_RW * 2;                            // 16-pixel MFMA row blocks per wave
+constexpr int DG_CB = 3;                                    // 16-pixel MFMA row blocks across the 34-pixel halo row (48 >= 34)
 static_assert(DG_TH % 4 == 0, "four waves split the rows");
 constexpr int DG_TILE_BYTES = (DG_TH + 2) * DG_IW * DG_PITCH;
-constexpr int DG_FRAGS = 9 * 2 * 2 * 12;                    // [tap][kstep][hi|lo][c * 4 + g], 16 bytes each
+constexpr int DG_FRAGS = 3 * 2 * 2 * 36;                    // [dy][kstep][hi|lo][(dxo * 3 + c) * 4 + g], 16 bytes each
 constexpr int DG_FRAG_WORDS = DG_FRAGS * 4;
+constexpr int DG_D_BYTES = 4 * DG_RW * (DG_CB * 16) * 16 * 4;   // per workgroup: [wave][row][pixel p'][column] fp32
 
 __global__ void pack_first_dgrad_fragments(const float* __restrict__ wf, uint32_t* __restrict__ frag) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;        // one bf16 pair per thread
   if (i >= DG_FRAG_WORDS) return;
-  const int q = i & 3, ent = (i >> 2) % 12, rest = (i >> 2) / 12;
-  const int part = rest & 1, ks = (rest >> 1) & 1, tap = rest >> 2;
-  const int c = ent >> 2, g = ent & 3;
+  const int q = i & 3, ent = (i >> 2) % 36, rest = (i >> 2) / 36;
+  const int part = rest & 1, ks = (rest >> 1) & 1, dyo = rest >> 2;
+  const int g = ent & 3, c = (ent >> 2) % 3, dxo = (ent >> 2) / 3;
+  const int tap = dyo * 3 + dxo;
   uint32_t out = 0;
   for (int e2 = 0; e2 < 2; ++e2) {
     const int n = ks * 32 + 8 * g + 2 * q + e2;
@@ -428,6 +434,7 @@ __global__ __launch_bounds__(256) void conv_first_dgrad_mfma(const bf16_t* __res
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* tile = smem;
   u32x4* wtab = reinterpret_cast<u32x4*>(smem + DG_TILE_BYTES);          // DG_FRAGS entries + one zero entry
+  float* dpatch = reinterpret_cast<float*>(smem + DG_TILE_BYTES + (DG_FRAGS + 1) * 16);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int tiles_x = (W + DG_TW - 1) / DG_TW;
@@ -453,9 +460,10 @@ __global__ __launch_bounds__(256) void conv_first_dgrad_mfma(const bf16_t* __res
   for (int i = tid; i < DG_FRAGS; i += 256) wtab[i] = *reinterpret_cast<const u32x4*>(frag + 4 * i);
   if (tid == 0) wtab[DG_FRAGS] = zero4;
   typedef __attribute__((ext_vector_type(4))) float acc_t;
-  // B column = lane & 15: columns 0..2 are the three image channels, the rest multiply zeros
-  const int ent = (r < 3) ? r * 4 + g : -1;
+  // B column = lane & 15 = 4 dxo + c (c < 3): nine live columns, the rest multiply zeros
+  const int ent = ((r & 3) < 3 && r < 12) ? ((r >> 2) * 3 + (r & 3)) * 4 + g : -1;
   const size_t plane = (size_t)H * W;
+  float* const dw = dpatch + wave * (DG_RW * DG_CB * 16 * 16);
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const int x0 = (t % tiles_x) * DG_TW, y0 = (t / tiles_x) * DG_TH;
     __syncthreads();                      // every wave is done reading the previous tile
@@ -466,39 +474,56 @@ __global__ __launch_bounds__(256) void conv_first_dgrad_mfma(const bf16_t* __res
     }
     if (t + (int)gridDim.x < ntiles) request(t + gridDim.x);
     __syncthreads();
-    acc_t acc[DG_MB];
+    acc_t acc[DG_RW][DG_CB];
 #pragma unroll
-    for (int mb = 0; mb < DG_MB; ++mb) acc[mb] = acc_t{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 1
-    for (int tap = 0; tap < 9; ++tap) {
-      const int dyo = tap / 3, dxo = tap - dyo * 3;
+    for (int rw = 0; rw < DG_RW; ++rw)
+#pragma unroll
+      for (int cb = 0; cb < DG_CB; ++cb) acc[rw][cb] = acc_t{0.0f, 0.0f, 0.0f, 0.0f};
+    // input rows wave * RW .. + RW + 1 of the halo tile feed output rows rw = ir - dyo
+#pragma unroll
+    for (int ir = 0; ir < DG_RW + 2; ++ir) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        const int fb = ((tap * 2 + ks) * 2) * 12;
-        const bf16x8v b_hi = __builtin_bit_cast(bf16x8v, wtab[ent >= 0 ? fb + ent : DG_FRAGS]);
-        const bf16x8v b_lo = __builtin_bit_cast(bf16x8v, wtab[ent >= 0 ? fb + 12 + ent : DG_FRAGS]);
+        bf16x8v a[DG_CB];
 #pragma unroll
-        for (int mb = 0; mb < DG_MB; ++mb) {
-          const int row = wave * DG_RW + (mb >> 1) + dyo, col = (mb & 1) * 16 + r + dxo;
-          const bf16x8v a = __builtin_bit_cast(
-              bf16x8v, *reinterpret_cast<const u32x4*>(tile + (row * DG_IW + col) * DG_PITCH + ks * 64 + g * 16));
-          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b_lo, acc[mb], 0, 0, 0);
-          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b_hi, acc[mb], 0, 0, 0);
+        for (int cb = 0; cb < DG_CB; ++cb) {
+          // pixel p' = 16 cb + r of the halo row (p' >= 34 reads past the row: those D rows are never used)
+          const int row = wave * DG_RW + ir, col = cb * 16 + r;
+          a[cb] = __builtin_bit_cast(bf16x8v, *reinterpret_cast<const u32x4*>(tile + (row * DG_IW + col) * DG_PITCH + ks * 64 + g * 16));
+        }
+#pragma unroll
+        for (int dyo = 0; dyo < 3; ++dyo) {
+          const int rw = ir - dyo;
+          if (rw < 0 || rw >= DG_RW) continue;
+          const int fb = ((dyo * 2 + ks) * 2) * 36;
+          const bf16x8v b_hi = __builtin_bit_cast(bf16x8v, wtab[ent >= 0 ? fb + ent : DG_FRAGS]);
+          const bf16x8v b_lo = __builtin_bit_cast(bf16x8v, wtab[ent >= 0 ? fb + 36 + ent : DG_FRAGS]);
+#pragma unroll
+          for (int cb = 0; cb < DG_CB; ++cb) {
+            acc[rw][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[cb], b_lo, acc[rw][cb], 0, 0, 0);
+            acc[rw][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[cb], b_hi, acc[rw][cb], 0, 0, 0);
+          }
         }
       }
     }
-    // D: column (lane & 15) = channel, rows 4g..4g+3 = pixels of the 16-pixel block
-    if (r < 3) {
+    // D: column (lane & 15) = 4 dxo + c, rows 4g..4g+3 = pixels p' of the block.  Through the wave's own
+    // LDS patch: dx[x][c] = D[x + 0][0, c] + D[x + 1][1, c] + D[x + 2][2, c]  (x = pixel of the 32-wide tile)
 #pragma unroll
-      for (int mb = 0; mb < DG_MB; ++mb) {
-        const int gy = y0 + wave * DG_RW + (mb >> 1);
-        if (gy >= H) continue;
+    for (int rw = 0; rw < DG_RW; ++rw)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int gx = x0 + (mb & 1) * 16 + 4 * g + i;
-          if (gx < W) dx[r * plane + (size_t)gy * W + gx] = acc[mb][i];
-        }
-      }
+      for (int cb = 0; cb < DG_CB; ++cb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dw[(rw * (DG_CB * 16) + cb * 16 + 4 * g + i) * 16 + r] = acc[rw][cb][i];
+    // (same wave wrote and reads: program order + the LDS counter suffice, no workgroup barrier)
+#pragma unroll
+    for (int k = 0; k < (DG_RW * 3 * DG_TW + 63) / 64; ++k) {
+      const int o = k * 64 + lane;                  // (row, channel, pixel): consecutive lanes = consecutive pixels
+      if (o >= DG_RW * 3 * DG_TW) break;
+      const int xl = o % DG_TW, c = (o / DG_TW) % 3, rw = o / (3 * DG_TW);
+      const float* base = dw + (rw * (DG_CB * 16) + xl) * 16 + c;
+      const float v = base[0] + base[16 + 4] + base[32 + 8];      // p' = xl + dxo, column 4 dxo + c
+      const int gy = y0 + wave * DG_RW + rw, gx = x0 + xl;
+      if (gy < H && gx < W) dx[c * plane + (size_t)gy * W + gx] = v;
     }
   }
 #endif
@@ -613,7 +638,7 @@ int dgrad_typed(const void* dy, const float* wf, const float* packed, float* dx,
                 hipStream_t st) {
   if (cin == 3 && cout == 64 && packed && std::is_same<T, bf16_t>::value && !getenv("STV_FIRST_VALU")) {
     const int tiles = ceil_div(W, DG_TW) * ceil_div(H, DG_TH);
-    constexpr int lds = DG_TILE_BYTES + (DG_FRAGS + 1) * 16;
+    constexpr int lds = DG_TILE_BYTES + (DG_FRAGS + 1) * 16 + DG_D_BYTES;
     static const int dg_wgs = getenv("STV_FIRST_DG_WGS") ? atoi(getenv("STV_FIRST_DG_WGS")) : 2;
     const int grid = tiles < dg_wgs * 256 ? tiles : dg_wgs * 256;   // resident workgroups walk the tiles
     hipLaunchKernelGGL(conv_first_dgrad_mfma, dim3(grid), dim3(256), lds, st, static_cast<const bf16_t*>(dy),
