@@ -270,14 +270,22 @@ __global__ __launch_bounds__(256) void conv_first_fwd_mfma(const float* __restri
   // stores overlap the split / MFMA / transpose work instead of bracketing it.
   constexpr int NPRE = (3 * MF_PLANE + 255) / 256;
   float pre[NPRE];
+  // which halo-tile element (channel, row, column) each of this thread's NPRE loads fetches is the same for
+  // every tile: decoded once (the divisions by the plane / row pitch were ~25 VALU per element per tile)
+  int pcyx[NPRE];
+#pragma unroll
+  for (int k = 0; k < NPRE; ++k) {
+    const int i = k * 256 + tid;
+    const int c = i / MF_PLANE, rem = i - c * MF_PLANE, py = rem / MF_IW, px = rem - py * MF_IW;
+    pcyx[k] = (i < 3 * MF_PLANE && px < MF_TW + 2) ? ((c << 16) | (py << 8) | px) : -1;
+  }
   auto request = [&](int t) {
     const int tx0 = (t % tiles_x) * MF_TW, ty0 = (t / tiles_x) * MF_TH;
 #pragma unroll
     for (int k = 0; k < NPRE; ++k) {
-      const int i = k * 256 + tid;
-      const int c = i / MF_PLANE, rem = i - c * MF_PLANE, py = rem / MF_IW, px = rem - py * MF_IW;
+      const int c = pcyx[k] >> 16, py = (pcyx[k] >> 8) & 255, px = pcyx[k] & 255;
       const int gy = ty0 + py - 1, gx = tx0 + px - 1;
-      const bool ok = i < 3 * MF_PLANE && px < MF_TW + 2 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      const bool ok = pcyx[k] >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W;
       pre[k] = ok ? x[((size_t)c * H + gy) * W + gx] : 0.0f;
     }
   };
@@ -445,14 +453,20 @@ __global__ __launch_bounds__(256) void conv_first_dgrad_mfma(const bf16_t* __res
   constexpr int NVEC = (DG_TH + 2) * DG_IW * 8;              // 16-byte vectors of a halo tile
   constexpr int NPRE = (NVEC + 255) / 256;
   u32x4 pre[NPRE];
+  int pyx[NPRE];            // (row << 8 | column) of the halo pixel behind each of this thread's loads: tile-independent
+#pragma unroll
+  for (int k = 0; k < NPRE; ++k) {
+    const int i = k * 256 + tid;
+    const int p = i >> 3;
+    pyx[k] = i < NVEC ? (((p / DG_IW) << 8) | (p % DG_IW)) : -1;
+  }
   auto request = [&](int t) {
     const int tx0 = (t % tiles_x) * DG_TW, ty0 = (t / tiles_x) * DG_TH;
 #pragma unroll
     for (int k = 0; k < NPRE; ++k) {
-      const int i = k * 256 + tid;
-      const int p = i >> 3, v = i & 7;
-      const int gy = ty0 + p / DG_IW - 1, gx = tx0 + p % DG_IW - 1;
-      const bool ok = i < NVEC && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      const int v = tid & 7;                                   // (k * 256 + tid) & 7
+      const int gy = ty0 + (pyx[k] >> 8) - 1, gx = tx0 + (pyx[k] & 255) - 1;
+      const bool ok = pyx[k] >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W;
       pre[k] = ok ? *reinterpret_cast<const u32x4*>(dy + ((size_t)gy * W + gx) * 64 + v * 8) : zero4;
     }
   };
