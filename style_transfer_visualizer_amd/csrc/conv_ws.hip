@@ -184,6 +184,92 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgrou
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
 
+  // ---- forward form: the epilogue of tile k runs in the shadow of tile k + 1's MFMAs ------------------
+  // One wave per SIMD has no other wave to overlap its epilogue with, but its own MFMAs leave seven of eight
+  // issue slots to the vector ALU.  At the end of a tile only the rounding (acc -> packed bf16 words Pp, 64
+  // VALU) happens in line; swaps, stores, the 2x2 pooling and its arg-max bytes are cut into twelve chunks
+  // that the next tile's column loop carries along, one per tap column.
+  typedef __attribute__((ext_vector_type(2))) short s16x2;
+  const s16x2 relu_lo = (s16x2)((short)(relu_out ? 0 : -32768));
+  uint32_t Pp[MT][8];
+  int py0 = 0, px0 = 0;
+  bool have_prev = false;
+  const bool pooling = !DG && a.pool != nullptr;
+  const int Hp = a.H >> 1, Wp = a.W >> 1;
+  const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(a.pool, 0, pooling ? Hp * Wp * a.cout * 2 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc(
+      a.pool_idx, 0, (pooling && a.pool_idx != nullptr) ? Hp * Wp * a.cout : 0, 0x00020000);
+  auto store_rows = [&](const uint32_t (&Q)[8], uint32_t poff, const __amdgpu_buffer_rsrc_t& rs_out) {
+#pragma unroll
+    for (int jp = 0; jp < 4; jp += 2) {
+      // lanes 32-63 of the group-jp register <-> lanes 0-31 of the group-(jp+1) register
+      const auto sx = __builtin_amdgcn_permlane32_swap(Q[jp], Q[jp + 1], false, false);
+      const auto sy = __builtin_amdgcn_permlane32_swap(Q[4 + jp], Q[4 + jp + 1], false, false);
+      const u32x4 out = {sx[0], sy[0], sx[1], sy[1]};
+      const int nn = nb + 8 * jp + 8 * h;
+      const uint32_t off = (poff != kOob && !(diag & 1)) ? poff + (uint32_t)(nn * 2) : kOob;
+      __builtin_amdgcn_raw_buffer_store_b128(out, rs_out, off, 0, 0);
+    }
+  };
+  auto right = [](uint32_t v) -> uint32_t {      // the neighbouring lane's word (quad_perm [1,0,3,2])
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);
+  };
+  auto gt = [](uint32_t best, uint32_t cand) -> uint32_t {    // bit 15 of each half: cand > best
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, best) - __builtin_bit_cast(s16x2, cand)) & 0x80008000u;
+  };
+  auto mx = [](uint32_t x, uint32_t y) -> uint32_t {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, x), __builtin_bit_cast(s16x2, y)));
+  };
+  uint32_t Qp[MT / 2][8], codep[MT / 2][8];
+  // chunk c of the pending tile's epilogue (c = 0..11): rows 0..3 of the full map, then the pooled map
+  auto deferred = [&](int c) {
+    if (c < MT) {
+      const int gy = py0 + wm * MT + c, gx = px0 + r;
+      store_rows(Pp[c], (gy < a.H && gx < a.W) ? (uint32_t)(((gy * a.W + gx) * a.cout) * 2) : kOob, rs_y);
+      return;
+    }
+    if (!pooling) return;
+    // Fused MaxPool2d(2,2) + arg-max byte map (stv.h: stv_conv_igemm_pool), on the STORED values: the
+    // packed bf16 words.  They are >= 0 here (the pool only rides behind a ReLU), so a bf16 compares like
+    // its 15-bit integer pattern and `b > a` is the sign of the packed difference a - b: two channels per
+    // instruction.  Window scan order (torch's first-maximum rule): top-left, top-right, bottom-left,
+    // bottom-right; the right column is the neighbouring lane.  Two of the 16 (window row, word) units per chunk.
+#pragma unroll
+    for (int u = 2 * (c - MT); u < 2 * (c - MT) + 2; ++u) {
+      const int mp = u >> 3, q = u & 7;
+      const uint32_t tl = Pp[2 * mp][q], bl = Pp[2 * mp + 1][q];
+      const uint32_t tr = right(tl), br = right(bl);
+      const uint32_t c1 = gt(tl, tr), m1 = mx(tl, tr);
+      const uint32_t c2 = gt(m1, bl), m2 = mx(m1, bl);
+      const uint32_t c3 = gt(m2, br), m3 = mx(m2, br);
+      Qp[mp][q] = m3;
+      // position of the first maximum: c3 ? 3 : c2 ? 2 : c1 ? 1 : 0  ->  bit1 = c2 | c3, bit0 = c3 | (c1 & ~c2)
+      const uint32_t b1 = c2 | c3;
+      const uint32_t b0 = (c2 & c3) | (~c2 & (c1 | c3));
+      // bit 2: the winner is positive (!= 0): adding 0x7FFF carries into bit 15 of a non-zero half
+      typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
+      const uint32_t pos = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, m3) + (u16x2)((unsigned short)0x7FFF)) & 0x80008000u;
+      codep[mp][q] = (b0 >> 15) | (b1 >> 14) | (pos >> 13);          // per half: a 3-bit code in bits 0-2 / 16-18
+    }
+    if (c == MT + 3 || c == MT + 7) {           // all eight words of a window row are done: store it
+      const int mp = (c - MT) >> 2;
+      const int gyp = ((py0 + wm * MT) >> 1) + mp, gxp = (px0 + r) >> 1;
+      const bool pix_ok = (r & 1) == 0 && gyp < Hp && gxp < Wp;
+      store_rows(Qp[mp], pix_ok ? (uint32_t)(((gyp * Wp + gxp) * a.cout) * 2) : kOob, rs_p);
+      if (a.pool_idx != nullptr) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          // channels e = 0,1 come from code[j] (bytes 0 and 2), e = 2,3 from code[4 + j]
+          const uint32_t word = __builtin_amdgcn_perm(codep[mp][4 + j], codep[mp][j], 0x06040200u);
+          const int nn = nb + 8 * j + 4 * h;
+          const uint32_t off = (pix_ok && !(diag & 1)) ? (uint32_t)((gyp * Wp + gxp) * a.cout + nn) : kOob;
+          __builtin_amdgcn_raw_buffer_store_b32(word, rs_i, off, 0, 0);
+        }
+      }
+    }
+  };
+  static_assert(MT == 4 && NSTAGE * 3 == 12, "twelve chunks: four map rows + eight pooling half-steps");
+
   int slot = 0;
   for (; t < ntiles; t += tstride, slot = (slot + 1 == NB) ? 0 : slot + 1) {
     char* const cur = smem + slot * WsLds<DG>::BUF;
@@ -228,11 +314,12 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgrou
         for (int mt = 0; mt < MT; ++mt)
           acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[s][dy * 3 + dx], af[col % 3][mt + dy], acc[mt], 0, 0, 0);
       if (col + 1 < NSTAGE * 3) relu_col((col + 1) % 3);
-      if (RELU_IN) {                                   // 12 MFMAs, 24 packed max: two in the shadow of each
+      if (!DG && have_prev) deferred(col);             // the previous tile's epilogue, one chunk per column
+      if (RELU_IN || !DG) {                            // 12 MFMAs with the packed max / epilogue VALU in their shadow
 #pragma unroll
         for (int k = 0; k < 12; ++k) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, DG ? 2 : 6, 0);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -276,103 +363,46 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgrou
     // ---- hand the buffer back: the next tile has landed, a later one starts streaming into this buffer.
     // Two buffers: everything this wave has in flight is drained (the DMA of the next tile and the
     // previous tile's stores were both issued a whole tile ago).  Three buffers: the DMA issued last
-    // (two tiles ahead) may stay in flight - loads retire in order, so "at most that DMA's pieces
-    // outstanding" implies the next tile has landed; stores are issued BEFORE the DMA of an iteration so
-    // that they can only make this counted wait longer, never satisfied early.
+    // (two tiles ahead) may stay in flight - loads retire in order among themselves, so "at most that
+    // DMA's IN_PIECES operations outstanding" implies every older load, i.e. the next tile, has landed.
+    // The previous tile's deferred stores count too: they can only make the wait longer, never satisfied
+    // early (the threshold is exactly the newest DMA's size).
     const bool more = t + NB * tstride < ntiles && !(diag & 2);
     if (NB == 3 && t + 2 * tstride < ntiles && !(diag & 2)) wait_vmcnt<IN_PIECES>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     if (NB == 2 && more) issue_tile(t + NB * tstride, cur);
 
-    // ---- epilogue in registers: round + ReLU on packed words, half-wave swap, 16-byte stores.
-    // (The bias already sits in the accumulators.)  P[mt][0..3] = channel pairs (0,1) of groups j,
-    // P[mt][4..7] = pairs (2,3): a lane holds channels nb + 8j + 4h + e of pixel (row mt, column r).
-    typedef __attribute__((ext_vector_type(2))) short s16x2;
-    const s16x2 relu_lo = (s16x2)((short)(relu_out ? 0 : -32768));
-    uint32_t P[MT][8];
+    if (NB == 3 && more) issue_tile(t + NB * tstride, cur);      // forward form: the stores follow in the next tile's shadow
+    // ---- rounding in line: acc -> packed bf16 words (ReLU after the rounding, on the packed words: a negative
+    // bf16 is a negative int16; the bias already sits in the accumulators).  P[mt][0..3] = channel pairs (0,1)
+    // of groups j, P[mt][4..7] = pairs (2,3): a lane holds channels nb + 8j + 4h + e of pixel (row mt, column r).
+    {
+      if (!DG && have_prev && (diag & 4)) {            // (timing knock-out without the MFMA loop: nothing carried the chunks)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        // ReLU after the rounding, on the packed words (a negative bf16 is a negative int16): same result
-        P[mt][j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(
-            __builtin_bit_cast(s16x2, pack_bf16x2(acc[mt][4 * j + 0], acc[mt][4 * j + 1])), relu_lo));
-        P[mt][4 + j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(
-            __builtin_bit_cast(s16x2, pack_bf16x2(acc[mt][4 * j + 2], acc[mt][4 * j + 3])), relu_lo));
+        for (int c = 0; c < 12; ++c) deferred(c);
       }
-    auto store_rows = [&](const uint32_t (&Q)[8], uint32_t poff, const __amdgpu_buffer_rsrc_t& rs_out) {
 #pragma unroll
-      for (int jp = 0; jp < 4; jp += 2) {
-        // lanes 32-63 of the group-jp register <-> lanes 0-31 of the group-(jp+1) register
-        const auto sx = __builtin_amdgcn_permlane32_swap(Q[jp], Q[jp + 1], false, false);
-        const auto sy = __builtin_amdgcn_permlane32_swap(Q[4 + jp], Q[4 + jp + 1], false, false);
-        const u32x4 out = {sx[0], sy[0], sx[1], sy[1]};
-        const int nn = nb + 8 * jp + 8 * h;
-        const uint32_t off = (poff != kOob && !(diag & 1)) ? poff + (uint32_t)(nn * 2) : kOob;
-        __builtin_amdgcn_raw_buffer_store_b128(out, rs_out, off, 0, 0);
-      }
-    };
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int gy = y0 + wm * MT + mt, gx = x0 + r;
-      store_rows(P[mt], (gy < a.H && gx < a.W) ? (uint32_t)(((gy * a.W + gx) * a.cout) * 2) : kOob, rs_y);
-    }
-
-    if (!DG && a.pool != nullptr) {
-      // Fused MaxPool2d(2,2) + arg-max byte map (stv.h: stv_conv_igemm_pool), on the STORED values: the
-      // packed bf16 words above.  They are >= 0 here (the pool only rides behind a ReLU), so a bf16
-      // compares like its 15-bit integer pattern and `b > a` is the sign of the packed difference
-      // a - b: two channels per instruction, no unpacking.  Window scan order (torch's first-maximum
-      // rule): top-left, top-right, bottom-left, bottom-right; the right column is the neighbouring lane.
-      const int Hp = a.H >> 1, Wp = a.W >> 1;
-      const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(a.pool, 0, Hp * Wp * a.cout * 2, 0x00020000);
-      const __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc(
-          a.pool_idx, 0, a.pool_idx != nullptr ? Hp * Wp * a.cout : 0, 0x00020000);
-      auto right = [](uint32_t v) -> uint32_t {      // the neighbouring lane's word (quad_perm [1,0,3,2])
-        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);
-      };
-      auto gt = [](uint32_t best, uint32_t cand) -> uint32_t {    // bit 15 of each half: cand > best
-        return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, best) - __builtin_bit_cast(s16x2, cand)) & 0x80008000u;
-      };
-      auto mx = [](uint32_t x, uint32_t y) -> uint32_t {
-        return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, x), __builtin_bit_cast(s16x2, y)));
-      };
-#pragma unroll
-      for (int mp = 0; mp < MT / 2; ++mp) {
-        const int gyp = ((y0 + wm * MT) >> 1) + mp, gxp = (x0 + r) >> 1;
-        const bool pix_ok = (r & 1) == 0 && gyp < Hp && gxp < Wp;
-        uint32_t Q[8], code[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const uint32_t tl = P[2 * mp][q], bl = P[2 * mp + 1][q];
-          const uint32_t tr = right(tl), br = right(bl);
-          const uint32_t c1 = gt(tl, tr), m1 = mx(tl, tr);
-          const uint32_t c2 = gt(m1, bl), m2 = mx(m1, bl);
-          const uint32_t c3 = gt(m2, br), m3 = mx(m2, br);
-          Q[q] = m3;
-          // position of the first maximum: c3 ? 3 : c2 ? 2 : c1 ? 1 : 0  ->  bit1 = c2 | c3, bit0 = c3 | (c1 & ~c2)
-          const uint32_t b1 = c2 | c3;
-          const uint32_t b0 = (c2 & c3) | (~c2 & (c1 | c3));
-          // bit 2: the winner is positive (!= 0): adding 0x7FFF carries into bit 15 of a non-zero half
-          typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
-          const uint32_t pos = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, m3) + (u16x2)((unsigned short)0x7FFF)) & 0x80008000u;
-          code[q] = (b0 >> 15) | (b1 >> 14) | (pos >> 13);          // per half: a 3-bit code in bits 0-2 / 16-18
+        for (int j = 0; j < 4; ++j) {
+          Pp[mt][j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(
+              __builtin_bit_cast(s16x2, pack_bf16x2(acc[mt][4 * j + 0], acc[mt][4 * j + 1])), relu_lo));
+          Pp[mt][4 + j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(
+              __builtin_bit_cast(s16x2, pack_bf16x2(acc[mt][4 * j + 2], acc[mt][4 * j + 3])), relu_lo));
         }
-        store_rows(Q, pix_ok ? (uint32_t)(((gyp * Wp + gxp) * a.cout) * 2) : kOob, rs_p);
-        if (a.pool_idx != nullptr) {
+      py0 = y0; px0 = x0;
+      if (DG) {                                        // backward form: stores right away (its buffers allow no third tile in flight)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            // channels e = 0,1 come from code[j] (bytes 0 and 2), e = 2,3 from code[4 + j]
-            const uint32_t word = __builtin_amdgcn_perm(code[4 + j], code[j], 0x06040200u);
-            const int nn = nb + 8 * j + 4 * h;
-            const uint32_t off = (pix_ok && !(diag & 1)) ? (uint32_t)((gyp * Wp + gxp) * a.cout + nn) : kOob;
-            __builtin_amdgcn_raw_buffer_store_b32(word, rs_i, off, 0, 0);
-          }
-        }
+        for (int c = 0; c < MT; ++c) deferred(c);
+      } else {
+        have_prev = true;
       }
     }
-    if (NB == 3 && more) issue_tile(t + NB * tstride, cur);
+  }
+  if (!DG && have_prev) {                              // the last tile's epilogue has no next tile to hide behind
+#pragma unroll
+    for (int c = 0; c < 12; ++c) deferred(c);
   }
   // every DMA issued was waited for inside the loop (the last two iterations issue none)
 #endif
