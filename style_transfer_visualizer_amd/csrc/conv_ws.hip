@@ -64,7 +64,7 @@ __device__ __forceinline__ bf16x8v relu_frag(bf16x8v v, uint32_t floor) {
   return __builtin_bit_cast(bf16x8v, __builtin_elementwise_max(__builtin_bit_cast(s16x8, v), lo));
 }
 
-template <bool DG, bool RELU_IN>
+template <bool DG, bool RELU_IN, bool POOL, bool MASKED = false, bool DUAL = false>
 __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgroups, int diag) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using lds_ptr = __attribute__((address_space(3))) void*;
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgrou
       }
   }
   bf16x8v sreg[NSTAGE];          // DG with a fused 1x1 term: S rows of this wave's channels (plain [cout][64])
-  const bool dual = DG && a.x2 != nullptr;
+  constexpr bool dual = DG && DUAL;                // (compile-time, like POOL: no branch between MFMA groups)
   if (DG) {
     const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w2), 0, dual ? 64 * 64 * 2 : 0, 0x00020000);
 #pragma unroll
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgrou
     }
 
   const bool relu_out = (a.flags & STV_RELU_OUT) != 0;
-  const bool do_mask = DG && (a.flags & STV_MASK) != 0;
+  constexpr bool do_mask = DG && MASKED;
   const int out_bytes = a.H * a.W * a.cout * 2;
   const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, out_bytes, 0x00020000);
 
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgrou
   uint32_t Pp[MT][8];
   int py0 = 0, px0 = 0;
   bool have_prev = false;
-  const bool pooling = !DG && a.pool != nullptr;
+  constexpr bool pooling = POOL;                   // compile-time: the chunks below must stay branch-free
   const int Hp = a.H >> 1, Wp = a.W >> 1;
   const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(a.pool, 0, pooling ? Hp * Wp * a.cout * 2 : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc(
@@ -222,10 +222,12 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgrou
   };
   uint32_t Qp[MT / 2][8], codep[MT / 2][8];
   // chunk c of the pending tile's epilogue (c = 0..11): rows 0..3 of the full map, then the pooled map
+  // (No branch on run-time state in here: the chunk has to sit in the same basic block as the MFMAs it
+  // hides behind.  Before the first tile `have_prev` is false and every store is aimed out of range.)
   auto deferred = [&](int c) {
     if (c < MT) {
       const int gy = py0 + wm * MT + c, gx = px0 + r;
-      store_rows(Pp[c], (gy < a.H && gx < a.W) ? (uint32_t)(((gy * a.W + gx) * a.cout) * 2) : kOob, rs_y);
+      store_rows(Pp[c], (have_prev && gy < a.H && gx < a.W) ? (uint32_t)(((gy * a.W + gx) * a.cout) * 2) : kOob, rs_y);
       return;
     }
     if (!pooling) return;
@@ -254,9 +256,9 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgrou
     if (c == MT + 3 || c == MT + 7) {           // all eight words of a window row are done: store it
       const int mp = (c - MT) >> 2;
       const int gyp = ((py0 + wm * MT) >> 1) + mp, gxp = (px0 + r) >> 1;
-      const bool pix_ok = (r & 1) == 0 && gyp < Hp && gxp < Wp;
+      const bool pix_ok = have_prev && (r & 1) == 0 && gyp < Hp && gxp < Wp;
       store_rows(Qp[mp], pix_ok ? (uint32_t)(((gyp * Wp + gxp) * a.cout) * 2) : kOob, rs_p);
-      if (a.pool_idx != nullptr) {
+      {                                              // (without a map the descriptor has no records: the stores drop)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           // channels e = 0,1 come from code[j] (bytes 0 and 2), e = 2,3 from code[4 + j]
@@ -314,8 +316,8 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgrou
         for (int mt = 0; mt < MT; ++mt)
           acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[s][dy * 3 + dx], af[col % 3][mt + dy], acc[mt], 0, 0, 0);
       if (col + 1 < NSTAGE * 3) relu_col((col + 1) % 3);
-      if (!DG && have_prev) deferred(col);             // the previous tile's epilogue, one chunk per column
-      if (RELU_IN || !DG) {                            // 12 MFMAs with the packed max / epilogue VALU in their shadow
+      if (!DG || col < MT) deferred(col);              // the previous tile's epilogue, one chunk per column
+      if (RELU_IN || !DG || col < MT) {                // 12 MFMAs with the packed max / epilogue VALU in their shadow
 #pragma unroll
         for (int k = 0; k < 12; ++k) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -378,9 +380,9 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgrou
     // bf16 is a negative int16; the bias already sits in the accumulators).  P[mt][0..3] = channel pairs (0,1)
     // of groups j, P[mt][4..7] = pairs (2,3): a lane holds channels nb + 8j + 4h + e of pixel (row mt, column r).
     {
-      if (!DG && have_prev && (diag & 4)) {            // (timing knock-out without the MFMA loop: nothing carried the chunks)
+      if (diag & 4) {                                  // (timing knock-out without the MFMA loop: nothing carried the chunks)
 #pragma unroll
-        for (int c = 0; c < 12; ++c) deferred(c);
+        for (int c = 0; c < (DG ? MT : 12); ++c) deferred(c);
       }
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
@@ -392,17 +394,12 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgrou
               __builtin_bit_cast(s16x2, pack_bf16x2(acc[mt][4 * j + 2], acc[mt][4 * j + 3])), relu_lo));
         }
       py0 = y0; px0 = x0;
-      if (DG) {                                        // backward form: stores right away (its buffers allow no third tile in flight)
-#pragma unroll
-        for (int c = 0; c < MT; ++c) deferred(c);
-      } else {
-        have_prev = true;
-      }
+      have_prev = true;
     }
   }
-  if (!DG && have_prev) {                              // the last tile's epilogue has no next tile to hide behind
+  {                                                    // the last tile's epilogue has no next tile to hide behind
 #pragma unroll
-    for (int c = 0; c < 12; ++c) deferred(c);
+    for (int c = 0; c < (DG ? MT : 12); ++c) deferred(c);
   }
   // every DMA issued was waited for inside the loop (the last two iterations issue none)
 #endif
@@ -421,9 +418,9 @@ int device_cus() {
   return cus[dev];
 }
 
-template <bool DG, bool RELU_IN>
+template <bool DG, bool RELU_IN, bool POOL, bool MASKED = false, bool DUAL = false>
 int launch_ws(const ConvArgs& a, hipStream_t st) {
-  if (stv_set_max_lds(reinterpret_cast<const void*>(&conv_ws_kernel<DG, RELU_IN>), WsLds<DG>::BYTES) != STV_OK) return STV_ERR_LAUNCH;
+  if (stv_set_max_lds(reinterpret_cast<const void*>(&conv_ws_kernel<DG, RELU_IN, POOL, MASKED, DUAL>), WsLds<DG>::BYTES) != STV_OK) return STV_ERR_LAUNCH;
   const int ntiles = ceil_div(a.W, TW) * ceil_div(a.H, TH);
   const int ncb = a.cout / 64;
   int per_cb = device_cus() / ncb;                   // one persistent workgroup per CU
@@ -431,7 +428,7 @@ int launch_ws(const ConvArgs& a, hipStream_t st) {
   if (per_cb > ntiles) per_cb = ntiles;
   const int n_wg = per_cb * ncb;
   const char* dg = getenv("STV_WS_DIAG");            // timing experiments only (results are then wrong)
-  hipLaunchKernelGGL((conv_ws_kernel<DG, RELU_IN>), dim3(n_wg), dim3(256), WsLds<DG>::BYTES, st, a, n_wg, dg ? atoi(dg) : 0);
+  hipLaunchKernelGGL((conv_ws_kernel<DG, RELU_IN, POOL, MASKED, DUAL>), dim3(n_wg), dim3(256), WsLds<DG>::BYTES, st, a, n_wg, dg ? atoi(dg) : 0);
   STV_CHECK_LAUNCH();
   return STV_OK;
 }
@@ -464,8 +461,14 @@ bool stv_conv_ws_supported(const ConvArgs& a, int dtype, int taps) {
 
 int stv_conv_ws_launch(const ConvArgs& a, hipStream_t st) {
   const bool has_f = (a.flags & STV_MASK) != 0 || a.x2 != nullptr;
-  if (!has_f) return (a.flags & STV_RELU_IN) ? launch_ws<false, true>(a, st) : launch_ws<false, false>(a, st);
+  if (!has_f) {
+    const bool relu = (a.flags & STV_RELU_IN) != 0, pool = a.pool != nullptr;
+    if (relu) return pool ? launch_ws<false, true, true>(a, st) : launch_ws<false, true, false>(a, st);
+    return pool ? launch_ws<false, false, true>(a, st) : launch_ws<false, false, false>(a, st);
+  }
   ConvArgs b = a;
   if (b.ref == nullptr) b.ref = b.x2;              // the z tile is fetched through `ref`
-  return launch_ws<true, false>(b, st);
+  const bool masked = (b.flags & STV_MASK) != 0, dual = b.x2 != nullptr;
+  if (masked) return dual ? launch_ws<true, false, false, true, true>(b, st) : launch_ws<true, false, false, true, false>(b, st);
+  return launch_ws<true, false, false, false, true>(b, st);       // has_f without a mask: the 1x1 term is there
 }
