@@ -56,8 +56,9 @@ def conv_flops(meta) -> float:
     return flops
 
 
-_CFG_NAMES = {0: "8, 128, 4, 2", 1: "8, 64, 4, 2", 2: "4, 128, 1, 4", 3: "4, 64, 2, 2", 4: "4, 64, 2, 2", 5: "8, 64, 4, 2", 6: "4, 64, 2, 2", 7: "2, 64, 2, 2", 8: "1, 64, 1, 2"}
-_CFG_KS = {0: "1, 3", 1: "1, 3", 2: "1, 3", 3: "1, 3", 4: "2, 3", 5: "1, 2", 6: "1, 2", 7: "2, 3", 8: "2, 3"}
+_CFG_NAMES = {0: "8, 128, 4, 2", 1: "8, 64, 4, 2", 2: "4, 128, 1, 4", 3: "4, 64, 2, 2", 4: "4, 64, 2, 2", 5: "8, 64, 4, 2", 6: "4, 64, 2, 2", 7: "2, 64, 2, 2", 8: "1, 64, 1, 2",
+              9: "16, 64, 4, 2", 10: "16, 64, 4, 2"}
+_CFG_KS = {0: "1, 3", 1: "1, 3", 2: "1, 3", 3: "1, 3", 4: "2, 3", 5: "1, 2", 6: "1, 2", 7: "2, 3", 8: "2, 3", 9: "1, 3", 10: "1, 2"}
 
 
 def kernel_group(meta, OP, dtype_code: int = 1, flags: int = 0) -> str | None:

@@ -84,6 +84,14 @@ int stv_conv_first_fwd_packed(const float* x_nchw, const float* packed, const fl
                               void* stream);
 int stv_conv_first_dgrad_packed(const void* dy, const float* packed, float* dx_nchw,
                                 int H, int W, int cin, int cout, int dtype, void* stream);
+/* Forward of a first layer that is a STYLE TAP (conv1_1 in the default layer set, core_model.py:213-226 /
+ * 297-314): besides y it leaves the split-K slabs of R = F^T F exactly as stv_gram_partial(y) would
+ * (stv_gram_ksplit(H*W, cout) slabs of [cout][cout] fp32 in `gram_partials`, to be reduced by
+ * stv_gram_finish / a stv_gram_multi tap with F == NULL), computed from the rounded values it stores, so the
+ * map is not read back for the Gram matrix.  bf16, cin = 3, cout = 64 only (stv_conv_first_gram_supported). */
+int stv_conv_first_gram_supported(int H, int W, int cin, int cout, int dtype);
+int stv_conv_first_fwd_gram(const float* x_nchw, const float* packed, const float* bias, void* y,
+                            float* gram_partials, int H, int W, int cin, int cout, int dtype, void* stream);
 
 /* Implicit-GEMM 3x3 conv, pad 1, stride 1, NHWC.  `w` is [taps][cout][cin] in
  * `dtype` (K-contiguous rows); bias fp32[cout] or NULL.  taps = 9 (3x3) or 1
@@ -194,7 +202,8 @@ int stv_gram_finish(const float* partials, const float* target, float* gram_out,
  * the slowest, not the sum.  Fields as the arguments of the two calls above; at most 8 taps.
  * Same arithmetic, same fixed summation order as the per-tap calls. */
 typedef struct {
-  const void* F;          /* features, NHWC [n_pixels][channels] in `dtype` */
+  const void* F;          /* features, NHWC [n_pixels][channels] in `dtype`; NULL: `partials` is already filled
+                             (stv_conv_first_fwd_gram) and only the finish pass runs for this tap */
   float* partials;        /* stv_gram_partials_bytes(n_pixels, channels) */
   const float* target;    /* [C][C] or NULL */
   float* gram_out;        /* [C][C] or NULL */
@@ -283,7 +292,8 @@ enum {
  * stream forked from / joined to the caller's stream with events. */
 enum { STV_LANE_SIDE = 1 << 29, STV_LANE_JOIN = 1 << 30 };
 /* Operands follow the direct entry points' argument order (inputs p0.., outputs q0..).
- * CONV_FIRST_FWD takes the optional stv_conv_first_pack buffer in p3, CONV_FIRST_DGRAD in p2;
+ * CONV_FIRST_FWD takes the optional stv_conv_first_pack buffer in p3 (and, with q1 set, runs
+ * stv_conv_first_fwd_gram with q1 = gram_partials), CONV_FIRST_DGRAD in p2;
  * CONV with q1 set runs stv_conv_igemm_pool (q1 = pooled output, q2 = optional arg-max map); CONV with q2 AND q3 set runs
  * stv_conv_igemm_dual (q2 = x2, q3 = w2, n = cin2: inputs, despite the slot names).
  * GRAM_MULTI: p0 = HOST pointer to an array of stv_gram_tap_t, n = its length; the array is

@@ -61,6 +61,8 @@ SIGNATURES = {
     "stv_conv_first_packed_bytes": (c_size_t, [c_int, c_int]),
     "stv_conv_first_pack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "stv_conv_first_fwd_packed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "stv_conv_first_gram_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "stv_conv_first_fwd_gram": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "stv_conv_first_dgrad_packed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "stv_conv_igemm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "stv_conv_igemm_pool": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,

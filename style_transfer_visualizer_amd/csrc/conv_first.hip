@@ -252,10 +252,22 @@ __global__ void pack_first_fragments(const float* __restrict__ wf, uint32_t* __r
   frag[i] = out;
 }
 
-__global__ __launch_bounds__(256) void conv_first_fwd_mfma(const float* __restrict__ x,
+// GRAM: the layer is a style tap - the kernel also leaves the split-K slabs of R = Y^T Y that
+// stv_gram_partial would compute from the stored map (one [64][64] fp32 slab per workgroup, slab index =
+// blockIdx.x), so the 134-MB map (1024^2) is not read back for it.  The Gram product contracts over
+// pixels while the accumulators hold [channel rows][pixel columns]: the packed words a lane is about to
+// store also go, pixel-major, into a 6-KB per-wave LDS patch, and ds_read_b64_tr_b16 hands them back as
+// [channel][8 pixels] operands (6 MFMAs per 32 pixels; wave-private, no barrier).  (First version: the
+// transposed accumulators from the same products with the MFMA operands swapped - no LDS at all, but 12
+// more MFMAs per 32 pixels: +20 us at 1024^2, as much as the separate Gram pass had cost.)
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+template <bool GRAM>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_first_fwd_mfma(const float* __restrict__ x,
                                                            const uint32_t* __restrict__ frag,
                                                            const float* __restrict__ bias,
-                                                           bf16_t* __restrict__ y, int H, int W) {
+                                                           bf16_t* __restrict__ y, float* __restrict__ gram_slabs,
+                                                           int H, int W) {
 #if defined(__HIP_DEVICE_COMPILE__)
   // [c][row][col]; every pixel value is stored already split: bf16 hi in the upper, bf16 lo (the
   // remainder) in the lower half of the word - split once here, not once per tap it is read for.
@@ -313,14 +325,23 @@ __global__ __launch_bounds__(256) void conv_first_fwd_mfma(const float* __restri
       koff[ks][e] = (k < 27) ? c * MF_PLANE + (tap / 3) * MF_IW + (tap % 3) : -1;
     }
   // accumulator layout (weights are the MFMA row operand): lane = pixel r, registers = channels
-  // nt * 32 + 8j + 4h + e of that pixel
-  f32x4 bv[2][4];
+  // nt * 32 + 8j + 4h + e of that pixel.  The accumulators START at the bias, read from LDS per row block
+  // (16 live registers fewer than carrying the lane's 32 bias values across tiles).
+  __shared__ __attribute__((aligned(16))) float sb[64];
+  if (tid < 64) sb[tid] = bias ? bias[tid] : 0.0f;
+  // Gram accumulators of this wave's pixels: 32x32 blocks (0,0), (0,1), (1,1) of the 64x64 matrix
+  // (rows c1 = 8(i>>2) + 4h + (i&3), column c2 = r: the layout stv_gram_partial's slabs are written from)
+  f32x16 gacc[3];
+  constexpr int GT_PITCH = 64 * 2 + 64;                 // bytes per pixel row of a patch; = 64 (mod 256): tr reads conflict-free
+  __shared__ __attribute__((aligned(16))) char gt_lds[GRAM ? 4 * 32 * GT_PITCH : 16];
+  char* const gpatch = gt_lds + (GRAM ? wave * 32 * GT_PITCH : 0);      // per wave: 32 pixels x 64 channels, no barrier needed
+  const int tr_lane = (((lane >> 4) >> 1) * 8 + ((lane & 15) >> 2)) * GT_PITCH + (((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2;
+  if (GRAM) {
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt)
+    for (int b = 0; b < 3; ++b)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) bv[nt][j][e] = bias ? bias[nt * 32 + 8 * j + 4 * h + e] : 0.0f;
+      for (int i = 0; i < 16; ++i) gacc[b][i] = 0.0f;
+  }
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
   const int x0 = (t % tiles_x) * MF_TW, y0 = (t / tiles_x) * MF_TH;
   __syncthreads();                       // every wave is done gathering from the previous tile
@@ -332,17 +353,19 @@ __global__ __launch_bounds__(256) void conv_first_fwd_mfma(const float* __restri
     }
   if (t + (int)gridDim.x < ntiles && !(STV_FIRST_DIAG & 4)) request(t + gridDim.x);
   __syncthreads();
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.0f;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     if (STV_FIRST_DIAG & 1) break;          // timing only: no gathers, no MFMAs
     const int base = (wave * 2 + mt) * MF_IW + r;
+    f32x16 acc[2];                          // one row block at a time: product, store, Gram (register budget of two waves per SIMD)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(&sb[nt * 32 + 8 * j + 4 * h]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[nt][4 * j + e] = b4[e];
+      }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       uint32_t hi4[4], lo4[4];
@@ -361,16 +384,14 @@ __global__ __launch_bounds__(256) void conv_first_fwd_mfma(const float* __restri
       const bf16x8v a_lo = __builtin_bit_cast(bf16x8v, (u32x4){lo4[0], lo4[1], lo4[2], lo4[3]});
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[0][ks][nt], a_lo, acc[mt][nt], 0, 0, 0);
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[1][ks][nt], a_hi, acc[mt][nt], 0, 0, 0);
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[0][ks][nt], a_hi, acc[mt][nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[0][ks][nt], a_lo, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[1][ks][nt], a_hi, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[0][ks][nt], a_hi, acc[nt], 0, 0, 0);
       }
     }
-  }
-  // epilogue in registers: bias, pack groups of 4 channels, trade groups with the partner
-  // half-wave (v_permlane32_swap) so that every lane stores 16 contiguous bytes - no LDS transpose
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+    // epilogue in registers: bias, pack groups of 4 channels, trade groups with the partner
+    // half-wave (v_permlane32_swap) so that every lane stores 16 contiguous bytes - no LDS transpose
+    {
     const int gy = y0 + wave * 2 + mt, gx = x0 + r;
     const bool ok = gy < H && gx < W;
     bf16_t* dst = y + ((size_t)gy * W + gx) * 64;
@@ -379,8 +400,8 @@ __global__ __launch_bounds__(256) void conv_first_fwd_mfma(const float* __restri
       uint32_t px[4], py[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        px[j] = pack_bf16x2(acc[mt][nt][4 * j] + bv[nt][j][0], acc[mt][nt][4 * j + 1] + bv[nt][j][1]);
-        py[j] = pack_bf16x2(acc[mt][nt][4 * j + 2] + bv[nt][j][2], acc[mt][nt][4 * j + 3] + bv[nt][j][3]);
+        px[j] = pack_bf16x2(acc[nt][4 * j], acc[nt][4 * j + 1]);
+        py[j] = pack_bf16x2(acc[nt][4 * j + 2], acc[nt][4 * j + 3]);
       }
 #pragma unroll
       for (int jp = 0; jp < 4; jp += 2) {
@@ -389,10 +410,58 @@ __global__ __launch_bounds__(256) void conv_first_fwd_mfma(const float* __restri
         const u32x4 out = {sx[0], sy[0], sx[1], sy[1]};     // lanes 0-31: channels 8jp..8jp+7, lanes 32-63: the next eight
         if (ok && !(STV_FIRST_DIAG & 2)) *reinterpret_cast<u32x4*>(dst + nt * 32 + 8 * jp + 8 * h) = out;
         if ((STV_FIRST_DIAG & 2) && out[0] == 0x12345678u) dst[0] = 1;   // keep the work alive
+        if (GRAM)      // the stored words, pixel-major, into this wave's patch (zeros for pixels outside the image)
+          *reinterpret_cast<u32x4*>(gpatch + r * GT_PITCH + (nt * 32 + 8 * jp + 8 * h) * 2) = ok ? out : (u32x4){0u, 0u, 0u, 0u};
+      }
+    }
+    if (GRAM) {
+      // R += Y^T Y over this row block's 32 pixels: operands [channel][8 pixels] straight from the patch with
+      // the hardware transpose read (the gram kernel's addressing, gram.hip: one 4x16 block per ds_read_b64_tr_b16)
+      typedef __attribute__((ext_vector_type(8))) short s16x8;
+      bf16x8v op[2][2];                      // [channel block][k-step of 16 pixels]
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          const char* pa = gpatch + tr_lane + kk * 16 * GT_PITCH + cb * 64;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pa));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pa + 4 * GT_PITCH));
+          const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          op[cb][kk] = __builtin_bit_cast(bf16x8v, v);
+        }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        gacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op[0][kk], op[0][kk], gacc[0], 0, 0, 0);
+        gacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op[0][kk], op[1][kk], gacc[1], 0, 0, 0);
+        gacc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op[1][kk], op[1][kk], gacc[2], 0, 0, 0);
       }
     }
   }
+  }
   }   // tiles
+  if (GRAM) {
+    // the four waves' sums meet in LDS in wave order (deterministic); block (1,0) is the mirror image of (0,1)
+    __shared__ float gs[64 * 64];
+#pragma unroll 1
+    for (int w = 0; w < 4; ++w) {
+      if (wave == w) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int row = (b == 2 ? 32 : 0) + 8 * (i >> 2) + 4 * h + (i & 3), col = (b == 0 ? 0 : 32) + r;
+            gs[row * 64 + col] = (w == 0 ? 0.0f : gs[row * 64 + col]) + gacc[b][i];
+          }
+      }
+      __syncthreads();
+    }
+    float* slab = gram_slabs + (size_t)blockIdx.x * (64 * 64);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int idx = k * 256 + tid, row = idx >> 6, col = idx & 63;
+      slab[idx] = (row >= 32 && col < 32) ? gs[col * 64 + row] : gs[idx];
+    }
+  }
 #endif
 }
 
@@ -610,16 +679,22 @@ float* first_scratch() {
 // `packed` (optional): the caller's buffer from stv_conv_first_pack - no per-call repack
 template <typename T>
 int fwd_typed(const float* x, const float* wf, const float* packed, const float* bias, void* y, int H, int W,
-              int cin, int cout, hipStream_t st) {
+              int cin, int cout, hipStream_t st, float* gram_slabs = nullptr) {
   if (cin == 3 && cout == 64 && packed && std::is_same<T, bf16_t>::value && !getenv("STV_FIRST_VALU")) {
     const int tiles = ceil_div(W, MF_TW) * ceil_div(H, MF_TH);
     static const int wg_per_cu = getenv("STV_FIRST_WGS") ? atoi(getenv("STV_FIRST_WGS")) : 2;   // swept 2..8: 2 is fastest at 512^2 and 1024^2
     const int grid = tiles < wg_per_cu * 256 ? tiles : wg_per_cu * 256;   // resident workgroups walk the tiles
-    hipLaunchKernelGGL(conv_first_fwd_mfma, dim3(grid), dim3(256), 0, st, x,
-                       reinterpret_cast<const uint32_t*>(packed + 2 * 1728), bias, static_cast<bf16_t*>(y), H, W);
+    const uint32_t* fr = reinterpret_cast<const uint32_t*>(packed + 2 * 1728);
+    if (gram_slabs)     // one slab per workgroup: exactly the split the finish kernel will walk (idle workgroups write zeros)
+      hipLaunchKernelGGL(conv_first_fwd_mfma<true>, dim3(stv_gram_ksplit(H * W, 64)), dim3(256), 0, st, x, fr, bias,
+                         static_cast<bf16_t*>(y), gram_slabs, H, W);
+    else
+      hipLaunchKernelGGL(conv_first_fwd_mfma<false>, dim3(grid), dim3(256), 0, st, x, fr, bias, static_cast<bf16_t*>(y),
+                         nullptr, H, W);
     STV_CHECK_LAUNCH();
     return STV_OK;
   }
+  if (gram_slabs) return STV_ERR_ARG;
   if (cin == 3 && cout == 64) {
     const float* wt = packed;
     if (!wt) {
@@ -724,6 +799,18 @@ extern "C" int stv_conv_first_fwd_packed(const float* x_nchw, const float* packe
   if (dtype == STV_F32) return fwd_typed<float>(x_nchw, packed, packed, bias, y, H, W, cin, cout, st);
   if (dtype == STV_BF16) return fwd_typed<bf16_t>(x_nchw, packed, packed, bias, y, H, W, cin, cout, st);
   return STV_ERR_ARG;
+}
+
+extern "C" int stv_conv_first_fwd_gram(const float* x_nchw, const float* packed, const float* bias, void* y,
+                                       float* gram_partials, int H, int W, int cin, int cout, int dtype, void* stream) {
+  if (!x_nchw || !packed || !y || !gram_partials || H <= 0 || W <= 0) return STV_ERR_ARG;
+  if (cin != 3 || cout != 64 || dtype != STV_BF16) return STV_ERR_ARG;     // the matrix-core first layer only
+  if (!stv_conv_first_gram_supported(H, W, cin, cout, dtype)) return STV_ERR_ARG;
+  return fwd_typed<bf16_t>(x_nchw, packed, packed, bias, y, H, W, cin, cout, static_cast<hipStream_t>(stream), gram_partials);
+}
+
+extern "C" int stv_conv_first_gram_supported(int H, int W, int cin, int cout, int dtype) {
+  return (cin == 3 && cout == 64 && dtype == STV_BF16 && H > 0 && W > 0 && !getenv("STV_FIRST_VALU")) ? 1 : 0;
 }
 
 extern "C" int stv_conv_first_dgrad_packed(const void* dy, const float* packed, float* dx_nchw, int H, int W,

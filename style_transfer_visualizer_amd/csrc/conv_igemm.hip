@@ -731,8 +731,8 @@ int launch_cfg(const ConvArgs& a, hipStream_t st) {
 // wave groups, 5 = 8x64 and 6 = 4x64 on a two-deep LDS ring (two / three workgroups per CU),
 // 7 = 2x64 with the K split (the 32x32-pixel layers: four times the workgroups of 4x64 x 2),
 // 8 = 1x64 with the K split in four-wave workgroups (a 32x32-pixel layer then covers all 256 CUs).  -1 = the shape is outside the matrix-core tiling (direct fallback).
-constexpr int kNumCfg = 9;
-const int kCfgTH[kNumCfg] = {8, 8, 4, 4, 4, 8, 4, 2, 1}, kCfgBN[kNumCfg] = {128, 64, 128, 64, 64, 64, 64, 64, 64};
+constexpr int kNumCfg = 11;     // 9 / 10 = 16x64 (four row blocks per wave: half the weight traffic per output) on the three- / two-deep ring
+const int kCfgTH[kNumCfg] = {8, 8, 4, 4, 4, 8, 4, 2, 1, 16, 16}, kCfgBN[kNumCfg] = {128, 64, 128, 64, 64, 64, 64, 64, 64, 64, 64};
 
 bool cfg_valid(int cfg, int cout) { return cfg >= 0 && cfg < kNumCfg && !(cout <= 64 && kCfgBN[cfg] == 128); }
 
@@ -793,6 +793,8 @@ int launch_mfma(const ConvArgs& a, int cfg, hipStream_t st) {
     case 6: return launch_cfg<Cfg<T, 4, 64, 2, 2, TAPS, 1, 2>>(a, st);
     case 7: return launch_cfg<Cfg<T, 2, 64, 2, 2, TAPS, 2>>(a, st);
     case 8: return launch_cfg<Cfg<T, 1, 64, 1, 2, TAPS, 2>>(a, st);
+    case 9: return launch_cfg<Cfg<T, 16, 64, 4, 2, TAPS>>(a, st);
+    case 10: return launch_cfg<Cfg<T, 16, 64, 4, 2, TAPS, 1, 2>>(a, st);
     default: return launch_cfg<Cfg<T, 4, 64, 2, 2, TAPS>>(a, st);
   }
 }

@@ -617,7 +617,7 @@ extern "C" int stv_gram_multi(const stv_gram_tap_t* taps, int n_taps, int dtype,
   const int vec = dtype == STV_F32 ? 4 : 8;
   for (int i = 0; i < n_taps; ++i) {
     const stv_gram_tap_t& t = taps[i];
-    if (!t.F || !t.partials || t.n_pixels <= 0 || t.channels <= 0 || t.channels % vec || t.norm <= 0.0f) return STV_ERR_ARG;
+    if (!t.partials || t.n_pixels <= 0 || t.channels <= 0 || t.channels % vec || t.norm <= 0.0f) return STV_ERR_ARG;
     if (dtype == STV_BF16 && (size_t)t.n_pixels * t.channels * 2 >= ((size_t)1 << 31)) return STV_ERR_ARG;
   }
   // partial sums: one launch per tile size present
@@ -625,7 +625,7 @@ extern "C" int stv_gram_multi(const stv_gram_tap_t* taps, int n_taps, int dtype,
     PartialMulti m{};
     for (int i = 0; i < n_taps; ++i) {
       const stv_gram_tap_t& t = taps[i];
-      if (gram_tile(t.channels) != TS) continue;
+      if (gram_tile(t.channels) != TS || !t.F) continue;      // F == NULL: the producer left the slabs (stv_conv_first_fwd_gram)
       const int nt = ceil_div(t.channels, TS), pairs = nt * (nt + 1) / 2;
       const int ksplit = stv_gram_ksplit(t.n_pixels, t.channels);
       const int pk = dtype == STV_BF16 ? PKB : PK;

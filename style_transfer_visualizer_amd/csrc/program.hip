@@ -26,6 +26,10 @@ int run_op(const stv_op_t& op, void* st) {
   o.flags &= ~(STV_LANE_SIDE | STV_LANE_JOIN);      // scheduling hints, not kernel flags
   switch (o.op) {
     case STV_OP_CONV_FIRST_FWD:   // p3 (optional): weights packed by stv_conv_first_pack
+      if (o.p3 && o.q1)    // the layer is a style tap: q1 = Gram slabs (stv_gram_partial's output, fused)
+        return stv_conv_first_fwd_gram(static_cast<const float*>(o.p0), static_cast<const float*>(o.p3),
+                                       static_cast<const float*>(o.p2), o.q0, static_cast<float*>(o.q1), o.H, o.W, o.cin,
+                                       o.cout, o.dtype, st);
       if (o.p3)
         return stv_conv_first_fwd_packed(static_cast<const float*>(o.p0), static_cast<const float*>(o.p3),
                                          static_cast<const float*>(o.p2), o.q0, o.H, o.W, o.cin, o.cout, o.dtype, st);

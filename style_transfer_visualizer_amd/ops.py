@@ -109,16 +109,27 @@ def conv_first_pack(wf: torch.Tensor) -> torch.Tensor:
     return packed
 
 
+def conv_first_gram_supported(H: int, W: int, cin: int, cout: int, dtype: torch.dtype) -> bool:
+    """True when the first layer can leave the Gram slabs of its own output (stv_conv_first_fwd_gram)."""
+    return bool(_lib.load().stv_conv_first_gram_supported(H, W, cin, cout, dtype_code(dtype)))
+
+
 def conv_first_fwd(x_nchw: torch.Tensor, wf: torch.Tensor, bias: torch.Tensor | None,
                    dtype: torch.dtype, out: torch.Tensor | None = None, *,
-                   packed: torch.Tensor | None = None) -> torch.Tensor:
-    """``packed`` (from :func:`conv_first_pack`) skips the per-call weight repack."""
+                   packed: torch.Tensor | None = None, gram_partials: torch.Tensor | None = None) -> torch.Tensor:
+    """``packed`` (from :func:`conv_first_pack`) skips the per-call weight repack.  ``gram_partials``
+    ([gram_ksplit(H*W, cout), cout, cout] fp32; needs ``packed``): also filled, as :func:`gram_partial` of the result would."""
     _, cin, H, W = x_nchw.shape
     cout = wf.shape[1]
     if out is None:
         out = torch.empty(H, W, cout, device=x_nchw.device, dtype=dtype)
     lib = _lib.load()
-    if packed is not None:
+    if gram_partials is not None:
+        if packed is None or tuple(gram_partials.shape) != (gram_ksplit(H * W, cout), cout, cout):
+            raise ValueError("gram_partials needs packed weights and [gram_ksplit(H*W, cout), cout, cout] slabs")
+        _lib.check(lib.stv_conv_first_fwd_gram(_ptr(x_nchw), _ptr(packed), _ptr(bias), _ptr(out), _ptr(gram_partials),
+                                               H, W, cin, cout, dtype_code(dtype), _stream()), "stv_conv_first_fwd_gram")
+    elif packed is not None:
         _lib.check(lib.stv_conv_first_fwd_packed(_ptr(x_nchw), _ptr(packed), _ptr(bias), _ptr(out), H, W, cin, cout,
                                                  dtype_code(dtype), _stream()), "stv_conv_first_fwd_packed")
     else:

@@ -69,6 +69,7 @@ class Tap:
     target: torch.Tensor | None = None
     # style
     partials: torch.Tensor | None = None
+    partials_fused: bool = False      # the producing conv fills `partials` itself (stv_conv_first_fwd_gram)
     sgrad: torch.Tensor | None = None
     parts_off: int = 0
     parts_cnt: int = 0
@@ -109,6 +110,7 @@ class Schedule:
         strip's own rows only (strip heights are multiples of 16, so no window straddles two strips)."""
         self.H, self.W, self.dtype, self.device = H, W, dtype, device
         self.halo = halo
+        self.fuse_first_gram = True      # off where the Gram runs over a sub-range of the buffer (spatial.SpatialShard)
         self.nodes: list[Node] = []
         self.style_taps: list[Tap] = []
         self.content_taps: list[Tap] = []
@@ -249,7 +251,22 @@ class Schedule:
                     out += after_node(nd)
                 continue
             if nd.kind == "conv_first":
-                out.append(self._op(op=OP_CONV_FIRST_FWD, p0=x, p1=nd.wf, p2=nd.bias, p3=nd.wb, q0=d.act,
+                # a tapped first layer leaves the Gram slabs of its own output (no second pass over the map)
+                slabs = None
+                tap = next((t for t in d.taps if t.kind == "style"), None)
+                if (tap is not None and nd.wb is not None and d.act.is_cuda and not self.halo and self.fuse_first_gram
+                        and os.environ.get("STV_FUSE_GRAM_FIRST", "1") != "0"
+                        and ops.conv_first_gram_supported(d.H, d.W, nd.cin, d.C, self.dtype)
+                        # one slab per workgroup: pays once a workgroup walks >= 4 tiles of 8 x 32 pixels (1024^2: 8,
+                        # -11 us; at 512^2, 2 tiles each, the slab reduction costs what the separate pass did)
+                        and (os.environ.get("STV_FUSE_GRAM_FIRST") == "2"
+                             or d.H * d.W >= 4 * 256 * ops.gram_ksplit(d.H * d.W, d.C))):
+                    if tap.partials is None:
+                        tap.partials = torch.empty(ops.gram_ksplit(d.H * d.W, d.C), d.C, d.C, device=self.device,
+                                                   dtype=torch.float32)
+                    slabs = tap.partials
+                    tap.partials_fused = True
+                out.append(self._op(op=OP_CONV_FIRST_FWD, p0=x, p1=nd.wf, p2=nd.bias, p3=nd.wb, q0=d.act, q1=slabs,
                                     H=d.H, W=d.W, cin=nd.cin, cout=d.C))
             elif nd.kind == "conv":
                 flags = ((RELU_IN if nd.relu_in else 0) | (RELU_OUT if d.relu_fused else 0)
@@ -274,7 +291,7 @@ class Schedule:
         if tap.partials is None:
             tap.partials = torch.empty(ops.gram_ksplit(n, b.C), b.C, b.C, device=self.device, dtype=torch.float32)
         out = []
-        if partial:
+        if partial and not tap.partials_fused:
             out.append(self._op(op=OP_GRAM_PARTIAL, p0=b.act, q0=tap.partials, n=n, cin=b.C))
         out.append(self._op(op=OP_GRAM_FINISH, p0=tap.partials, p1=target, p2=coef_dev, q0=gram_out, q1=loss_part,
                             q2=sgrad, n=n, cin=b.C, f0=GRAM_CLAMP_MAX, f1=float(b.C * n), f2=coef))
@@ -296,7 +313,7 @@ class Schedule:
             n = b.H * b.W
             if tap.partials is None:
                 tap.partials = torch.empty(ops.gram_ksplit(n, b.C), b.C, b.C, device=self.device, dtype=torch.float32)
-            e.F, e.partials = ptr(b.act), ptr(tap.partials)
+            e.F, e.partials = (None if tap.partials_fused else ptr(b.act)), ptr(tap.partials)
             e.target, e.gram_out, e.loss_part = ptr(sp.get("target")), ptr(sp.get("gram_out")), ptr(sp.get("loss_part"))
             e.sgrad, e.coef_dev = ptr(sp.get("sgrad")), ptr(sp.get("coef_dev"))
             e.n_pixels, e.channels = n, b.C

@@ -60,6 +60,7 @@ class SpatialShard:
         self.style_w, self.content_w = float(style_w), float(content_w)
         He = self.e1 - self.e0
         self.sched = s = plan.Schedule(layers, style_at, content_at, He, W, dtype, dev, with_grad=True)
+        s.fuse_first_gram = False        # the Gram sums run over the strip's core rows only (below)
         self.x_ext = torch.zeros(1, 3, He, W, device=dev)
         self.g_ext = torch.zeros(1, 3, He, W, device=dev)
 

@@ -307,6 +307,28 @@ def test_bf16_storage_tracks_fp32(monkeypatch):
     assert err < 0.1, f"bf16 gradient drifted {err:.3f} of scale"
 
 
+def test_first_layer_gram_fusion_is_equivalent(monkeypatch):
+    """bf16 mode, conv1_1 tapped: the first layer leaving its own Gram slabs (stv_conv_first_fwd_gram, forced
+    on at this small size) against the separate Gram pass - same targets and losses up to the fp32 summation
+    order of the slabs, same gradient up to what a last-bit change of the bf16 seed S moves."""
+    case = GoldenCase("vgg19_white_lbfgs")
+    m = case.meta
+    out = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("STV_FUSE_GRAM_FIRST", mode)
+        _, model, x, _ = _build(case, monkeypatch, precision="bf16")
+        s, c, tot = model.loss_and_grad(x, m["style_w"], m["content_w"])
+        first = next(iter(model._engines.values())).sched.style_taps[0]
+        assert first.partials_fused == (mode == "2")
+        out[mode] = (float(s), float(c), x.grad.clone(), model.style_targets[0].clone())
+    assert torch.allclose(out["0"][3], out["2"][3], rtol=0, atol=2e-6 * float(out["0"][3].abs().max()))
+    assert out["2"][0] == pytest.approx(out["0"][0], rel=2e-5)
+    assert out["2"][1] == out["0"][1]                                   # the content term does not see the Gram chain
+    err = float((out["2"][2] - out["0"][2]).abs().max() / out["0"][2].abs().max())
+    record_parity("vgg19_white_lbfgs bf16", "gradient, fused first-layer Gram vs separate pass (of scale)", err, 2e-2)
+    assert err < 2e-2
+
+
 def test_oracle_agreement_at_larger_size(monkeypatch):
     """Same seeded inputs through oracle (CPU) and HIP at 160x128 with the mini net."""
     case = GoldenCase("mini_white_lbfgs")

@@ -78,6 +78,39 @@ def test_conv_first_fwd_and_dgrad(dtype, hw, packed):
     assert_close(dx, xr.grad, torch.float32, 9 * cout, "conv_first_dgrad")
 
 
+@pytest.mark.parametrize("hw", [(64, 64), (75, 101), (13, 7), (8, 32), (256, 320), (512, 512)])
+def test_conv_first_fwd_leaves_gram_slabs(hw):
+    """stv_conv_first_fwd_gram: the tapped first layer also writes the split-K slabs of F^T F that
+    stv_gram_partial computes from the stored map - same map bit for bit, same Gram matrix up to the
+    fp32 summation order (ragged tiles, single-tile images, idle workgroups that must write zero slabs)."""
+    H, W = hw
+    x = rnd((1, 3, H, W), 301, -2, 2)
+    w = rnd((64, 3, 3, 3), 302, -0.5, 0.5)
+    b = rnd((64,), 303, -0.1, 0.1)
+    wf = ops.pack_weights_fwd(w).to(DEV)
+    pk = ops.conv_first_pack(wf)
+    assert ops.conv_first_gram_supported(H, W, 3, 64, torch.bfloat16)
+    y_plain = ops.conv_first_fwd(x.to(DEV), wf, b.to(DEV), torch.bfloat16, packed=pk)
+    slabs = torch.full((ops.gram_ksplit(H * W, 64), 64, 64), float("nan"), device=DEV)
+    y = ops.conv_first_fwd(x.to(DEV), wf, b.to(DEV), torch.bfloat16, packed=pk, gram_partials=slabs)
+    assert torch.equal(y, y_plain)
+    assert bool(torch.isfinite(slabs).all())
+    got = slabs.double().sum(0).cpu()
+    f = y.reshape(H * W, 64).double().cpu()
+    want = f.t() @ f                                    # Gram of the STORED values, in float64
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 2e-6 * scale, f"{float((got - want).abs().max()) / scale:.2e}"
+    assert torch.equal(got, got.t())                    # the lower block is written as the mirror image
+    # and through the finish pass it is the Gram matrix the separate chain produces
+    g_fused = torch.empty(64, 64, device=DEV)
+    ops.gram_finish(slabs, H * W, 64, gram_out=g_fused, clamp_max=5e5, norm=float(64 * H * W))
+    g_chain = torch.empty(64, 64, device=DEV)
+    ops.gram_finish(ops.gram_partial(y), H * W, 64, gram_out=g_chain, clamp_max=5e5, norm=float(64 * H * W))
+    assert float((g_fused - g_chain).abs().max()) <= 2e-6 * float(g_chain.abs().max())
+    with pytest.raises(ValueError):
+        ops.conv_first_fwd(x.to(DEV), wf, b.to(DEV), torch.bfloat16, gram_partials=slabs)      # needs packed weights
+
+
 CONV_CASES = [
     # cin, cout, H, W
     (64, 64, 33, 70),
@@ -131,7 +164,7 @@ def test_conv_igemm_forward(dtype, case, flags, blocked):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [None, 0, 1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("cfg", [None, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 @pytest.mark.parametrize("flags", [0, ops.MASK, ops.ACCUM, ops.MASK | ops.ACCUM])
 @pytest.mark.parametrize("case", [(128, 64, 33, 70), (256, 128, 16, 40), (64, 64, 9, 33), (512, 256, 8, 8),
                                   (96, 48, 20, 36)])   # 48 channels: not whole multi-slice stages -> general 1x1 loop
@@ -163,7 +196,7 @@ def test_conv_igemm_dual_dgrad_plus_gram_term(dtype, cfg, flags, case, monkeypat
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [None, 0, 1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("cfg", [None, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 @pytest.mark.parametrize("case", [(64, 64, 33, 70), (128, 128, 16, 40), (64, 128, 9, 33), (256, 256, 8, 8)])
 def test_conv_igemm_with_fused_maxpool(dtype, cfg, case, monkeypatch):
     """One launch writes relu(conv) and MaxPool2d(2,2) of it (odd sizes drop the last row / column like torch)."""
@@ -256,7 +289,7 @@ def test_conv_ws_forward_pool_and_backward(case, monkeypatch):
         assert_close(ops.from_nhwc(out), xr.grad * (zq > 0).float(), dtype, 9 * 64, f"ws masked dgrad {case}")
 
 
-@pytest.mark.parametrize("cfg", [None, 0, 1, 3, 4, 5, 7, 8])
+@pytest.mark.parametrize("cfg", [None, 0, 1, 3, 4, 5, 7, 8, 9, 10])
 @pytest.mark.parametrize("case", [(128, 64, 32, 64), (256, 128, 16, 40), (512, 512, 8, 8), (512, 256, 12, 20)])
 def test_conv_igemm_route_equals_dgrad_then_pool_backward(cfg, case, monkeypatch):
     """stv_conv_igemm_route: the dgrad of the conv behind a max-pool writes the pre-pool gradient directly.
@@ -313,7 +346,7 @@ def test_conv_ws_matches_the_general_kernel(monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 @pytest.mark.parametrize("case", [(128, 128, 21, 70), (64, 64, 9, 33), (48, 136, 12, 40), (512, 128, 8, 8)])
 def test_conv_igemm_every_tile_config(dtype, cfg, case, monkeypatch):
     """Each tile shape / wave layout / K split (forced with STV_CONV_CFG) on full, ragged and odd-K shapes."""

@@ -25,7 +25,7 @@ for k, C in ((1, 64), (2, 128), (4, 256), (8, 512)):
     idx = torch.empty(H // 2, H // 2, C, device=dev, dtype=torch.uint8)
     w2 = (torch.randn(C, C, device=dev) * 0.02).bfloat16()
     rows = {}
-    for cfg in range(9):
+    for cfg in range(11):
         if C <= 64 and cfg in (0, 2):
             continue
         os.environ["STV_CONV_CFG"] = str(cfg)
