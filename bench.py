@@ -68,7 +68,8 @@ def kernel_group(meta, OP, dtype_code: int = 1, flags: int = 0) -> str | None:
     if op == OP["CONV"]:
         if taps == 9 and _lib.load().stv_conv_uses_ws(H, W, cin, cout, taps, dtype_code, 0, 1 if _n > 0 else 0, 0):
             return f"conv_ws_kernel<{'true' if _n > 0 else 'false'}>"      # weight-stationary persistent kernel (Cin = 64)
-        cfg = _lib.load().stv_conv_config(H, W, cin, cout, taps, dtype_code)
+        # (a dgrad with the pooling backward in its epilogue has its own tune-table entry: stv.h STV_TUNE_ROUTE)
+        cfg = _lib.load().stv_conv_config(H, W, cin, cout, 109 if (flags & _lib.POOL_ROUTE) else taps, dtype_code)
         elem = "unsigned short" if dtype_code == 1 else "float"
         if cfg < 0:
             return f"conv_direct_kernel<{elem}, {taps}>"

@@ -109,7 +109,10 @@ int stv_conv_first_fwd_gram(const float* x_nchw, const float* packed, const floa
  * the direct kernel (nothing to tune), or -(100 + STV_ERR_*) on failure.
  * Synchronises `stream`.  STV_CONV_TUNE=0 in the environment disables measuring.
  * Different tiles sum K in different orders: results agree to fp32 rounding, not
- * bit for bit, across configurations. */
+ * bit for bit, across configurations.
+ * taps = STV_TUNE_ROUTE (bf16): the shape is measured as stv_conv_igemm_route runs it (dgrad + pooling backward in
+ * the epilogue, 2H x 2W output) and remembered under its own key - the routed epilogue prefers smaller tiles. */
+#define STV_TUNE_ROUTE 109
 int stv_conv_tune(int H, int W, int cin, int cout, int taps, int dtype, void* stream);
 int stv_conv_igemm(const void* x, const void* w, const float* bias, const void* ref,
                    void* y, int H, int W, int cin, int cout, int taps, int flags,

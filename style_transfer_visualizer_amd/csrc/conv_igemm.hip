@@ -767,6 +767,12 @@ int model_cfg(int H, int W, int cin, int cout) {
   return best;
 }
 
+// Tune-table key of the dgrad with the pooling backward in its epilogue (stv_conv_igemm_route): the routed
+// epilogue writes four output pixels per accumulator pixel and wants smaller tiles than the plain conv of
+// the same shape (round-2 sweep, tools/route_sweep.py: 512^2 128->64 64 us on 4x64 against 87 on 16x64,
+// the plain conv's pick; 256^2 256->128 48 against 59 on 8x128), so it is measured as its own "shape".
+constexpr int kRouteTaps = STV_TUNE_ROUTE;
+
 int choose_cfg(int H, int W, int cin, int cout, int elem_bytes, int taps = 9) {
   const int kVec = 16 / elem_bytes, CK = 32 / elem_bytes;
   if ((cin % CK) || (cout % kVec)) return -1;
@@ -778,7 +784,9 @@ int choose_cfg(int H, int W, int cin, int cout, int elem_bytes, int taps = 9) {
   // measured the shape already (tests that assert near fp32 rounding want one summation order)
   const char* tune = getenv("STV_CONV_TUNE");
   const int t = (tune && atoi(tune) == 0) ? -1 : tuned_cfg(H, W, cin, cout, taps, elem_bytes);
-  return t >= 0 ? t : model_cfg(H, W, cin, cout);
+  if (t >= 0) return t;
+  const int m = model_cfg(H, W, cin, cout);
+  return (taps == kRouteTaps && (m == 0 || m == 2)) ? 3 : m;       // untuned routed dgrad: 4x64 where the model says 128-wide
 }
 
 template <typename T, int TAPS>
@@ -825,23 +833,32 @@ __global__ void tune_fill_kernel(uint32_t* p, size_t n_words, uint32_t seed) {
 }
 
 template <typename T>
-int tune_typed(int H, int W, int cin, int cout, int taps, hipStream_t st) {
-  const size_t nx = (size_t)H * W * cin, nw = (size_t)taps * cout * cin, ny = (size_t)H * W * cout;
+int tune_typed(int H, int W, int cin, int cout, int key_taps, hipStream_t st) {
+  const bool route = key_taps == kRouteTaps;       // (bf16 only: the caller checked)
+  const int taps = route ? 9 : key_taps;
+  const size_t nx = (size_t)H * W * cin, nw = (size_t)taps * cout * cin, ny = (size_t)H * W * cout * (route ? 4 : 1);
   char* buf = nullptr;
   const size_t bx = (nx * sizeof(T) + 255) / 256 * 256, bw = (nw * sizeof(T) + 255) / 256 * 256;
-  if (hipMalloc(reinterpret_cast<void**>(&buf), bx + bw + ny * sizeof(T)) != hipSuccess) {
+  const size_t bi = route ? ((size_t)H * W * cout + 255) / 256 * 256 : 0;       // arg-max byte map
+  if (hipMalloc(reinterpret_cast<void**>(&buf), bx + bw + bi + ny * sizeof(T)) != hipSuccess) {
     (void)hipGetLastError();                       // no room for scratch copies: keep the analytic choice
-    return model_cfg(H, W, cin, cout);
+    return choose_cfg(H, W, cin, cout, (int)sizeof(T), key_taps);
   }
-  const size_t words = (bx + bw) / 4;
+  const size_t words = (bx + bw + bi) / 4;         // (random map bytes: codes 0..255, the routing compares and masks as usual)
   hipLaunchKernelGGL(tune_fill_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st,
                      reinterpret_cast<uint32_t*>(buf), words, 0x9E3779B9u);
-  ConvArgs a{buf, buf + bx, nullptr, nullptr, buf + bx + bw, H, W, cin, cout, STV_W_BLOCKED, nullptr, nullptr, nullptr, nullptr, 0};
+  ConvArgs a{buf, buf + bx, nullptr, nullptr, buf + bx + bw + bi, H, W, cin, cout, STV_W_BLOCKED, nullptr, nullptr, nullptr, nullptr, 0};
   if (taps == 1) a.flags = 0;
+  if (route) {
+    a.flags |= STV_MASK;
+    a.route_idx = buf + bx + bw;
+    a.route_out = a.y;
+  }
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);
-  const int base = model_cfg(H, W, cin, cout);
+  const int base = route ? ((model_cfg(H, W, cin, cout) == 0 || model_cfg(H, W, cin, cout) == 2) ? 3 : model_cfg(H, W, cin, cout))
+                         : model_cfg(H, W, cin, cout);
   int best = base;
   float t_best = 3.4e38f, t_base = 3.4e38f;
   int rc = STV_OK;
@@ -878,11 +895,11 @@ int tune_typed(int H, int W, int cin, int cout, int taps, hipStream_t st) {
   if (best != base && t_best > 0.97f * t_base) best = base;
   std::lock_guard<std::mutex> lk(g_tune_mu);
   for (TuneEntry& e : g_tune)
-    if (e.H == H && e.W == W && e.cin == cin && e.cout == cout && e.taps == taps && e.esize == (int)sizeof(T)) {
+    if (e.H == H && e.W == W && e.cin == cin && e.cout == cout && e.taps == key_taps && e.esize == (int)sizeof(T)) {
       e.cfg = best;
       return best;
     }
-  g_tune.push_back(TuneEntry{H, W, cin, cout, taps, (int)sizeof(T), best});
+  g_tune.push_back(TuneEntry{H, W, cin, cout, key_taps, (int)sizeof(T), best});
   return best;
 }
 
@@ -901,9 +918,11 @@ extern "C" int stv_conv_uses_ws(int H, int W, int cin, int cout, int taps, int d
 }
 
 extern "C" int stv_conv_tune(int H, int W, int cin, int cout, int taps, int dtype, void* stream) {
-  if (H <= 0 || W <= 0 || cin <= 0 || cout <= 0 || (taps != 9 && taps != 1)) return -(100 + STV_ERR_ARG);
+  if (H <= 0 || W <= 0 || cin <= 0 || cout <= 0 || (taps != 9 && taps != 1 && taps != kRouteTaps)) return -(100 + STV_ERR_ARG);
   if (dtype != STV_F32 && dtype != STV_BF16) return -(100 + STV_ERR_ARG);
+  if (taps == kRouteTaps && dtype != STV_BF16) return -(100 + STV_ERR_ARG);
   if ((size_t)H * W * (size_t)(cin > cout ? cin : cout) >= (size_t)1 << 31) return -(100 + STV_ERR_ARG);
+  if (taps == kRouteTaps && (size_t)4 * H * W * (size_t)cout * 2 >= (size_t)1 << 31) return -(100 + STV_ERR_ARG);
   const int esize = dtype == STV_BF16 ? 2 : 4;
   if ((cin % (32 / esize)) || (cout % (16 / esize))) return -1;          // direct-kernel shape: nothing to tune
   if (const char* off = getenv("STV_CONV_TUNE"))
@@ -953,12 +972,12 @@ extern "C" int stv_conv_igemm_route(const void* x, const void* w, const void* po
   if (flags & (STV_RELU_IN | STV_RELU_OUT | STV_ACCUM)) return STV_ERR_ARG;
   // 32-bit buffer offsets: the input (H x W x cin) and the routed output (2H x 2W x cout), bf16
   if ((size_t)H * W * (size_t)cin * 2 >= (size_t)1 << 31 || (size_t)4 * H * W * (size_t)cout * 2 >= (size_t)1 << 31) return STV_ERR_ARG;
-  if (choose_cfg(H, W, cin, cout, 2, 9) < 0) return STV_ERR_ARG;
+  if (choose_cfg(H, W, cin, cout, 2, kRouteTaps) < 0) return STV_ERR_ARG;
   ConvArgs a{x, w, nullptr, nullptr, y_full, H, W, cin, cout, flags, nullptr, nullptr, nullptr, nullptr, 0};
   a.route_idx = pool_idx;
   a.route_out = y_full;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  int cfg = choose_cfg(H, W, cin, cout, 2, 9);
+  int cfg = choose_cfg(H, W, cin, cout, 2, kRouteTaps);
   return launch_mfma<bf16_t, 9>(a, cfg, st);                                   // always the general kernel
 }
 

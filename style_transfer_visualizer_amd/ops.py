@@ -81,8 +81,12 @@ def conv_uses_ws(H: int, W: int, cin: int, cout: int, dtype: torch.dtype, *, fla
     return bool(_lib.load().stv_conv_uses_ws(H, W, cin, cout, 9, dtype_code(dtype), flags, int(has_ref), int(has_pool)))
 
 
+TUNE_ROUTE = 109      # stv.h STV_TUNE_ROUTE: `taps` value that tunes the shape as conv_igemm_route runs it
+
+
 def conv_tune(H: int, W: int, cin: int, cout: int, taps: int, dtype: torch.dtype) -> int:
-    """Measure the tile configurations for one conv shape once (stv_conv_tune); returns the choice (-1: direct kernel)."""
+    """Measure the tile configurations for one conv shape once (stv_conv_tune); returns the choice (-1: direct kernel).
+    ``taps=TUNE_ROUTE``: the dgrad with the pooling backward in its epilogue (its own table entry)."""
     r = int(_lib.load().stv_conv_tune(H, W, cin, cout, taps, dtype_code(dtype), _stream()))
     if r < -1:
         _lib.check(-r - 100, "stv_conv_tune")

@@ -392,6 +392,8 @@ class Schedule:
                         and 4 * s.act.numel() * s.act.element_size() < 2 ** 31
                         and d.grad.numel() * d.grad.element_size() < 2 ** 31):
                     ps = pool_nd.src
+                    if d.grad.is_cuda:
+                        ops.conv_tune(s.H, s.W, d.C, s.C, ops.TUNE_ROUTE, self.dtype)     # cached per shape
                     rflags = (MASK if (ps.relu_fused and not ps.taps) else 0) | W_BLOCKED | POOL_ROUTE
                     out.append(self._op(op=OP_CONV, p0=d.grad, p1=nd.wb, p2=pool_nd.idx, q1=ps.grad, H=s.H, W=s.W,
                                         cin=d.C, cout=s.C, taps=9, flags=rflags))
