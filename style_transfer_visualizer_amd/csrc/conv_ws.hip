@@ -272,38 +272,48 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgrou
   };
   static_assert(MT == 4 && NSTAGE * 3 == 12, "twelve chunks: four map rows + eight pooling half-steps");
 
+  // A fragments: three column sets in flight.  The first two columns of a tile are requested as soon as the tile
+  // has landed - for every tile but the first that is right behind the barrier at the end of the previous
+  // one, so their LDS round trip runs under that tile's rounding VALU instead of in front of the first MFMA.
+  bf16x8v af[3][AROWS];
+  auto load_col_from = [&](const char* buf, int col, int set) {          // col = stage * 3 + dx
+    const int s = col / 3, dx = col - s * 3;
+#pragma unroll
+    for (int j = 0; j < AROWS; ++j)
+      af[set][j] = *reinterpret_cast<const bf16x8v*>(buf + s * IN_STAGE + a_addr[dx][j]);
+  };
+  f32x16 acc0;                                       // C operand of a tile's first MFMAs: the bias (forward) / zero
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc0[i] = DG ? 0.0f : bias_v[i >> 2][i & 3];
+  if (t < ntiles) {
+    load_col_from(smem, 0, 0);
+    load_col_from(smem, 1, 1);
+  }
   int slot = 0;
   for (; t < ntiles; t += tstride, slot = (slot + 1 == NB) ? 0 : slot + 1) {
     char* const cur = smem + slot * WsLds<DG>::BUF;
     const int ty = t / tiles_x, tx = t - ty * tiles_x;
     const int y0 = ty * TH, x0 = tx * TW;
 
-    // accumulators start at the bias (zero for a backward pass): the epilogue has no add left
+    // accumulators start at the bias (zero for a backward pass): the epilogue has no add left.  Not as 64
+    // moves per tile: the first MFMA of each row block takes the bias registers as its C operand.
     f32x16 acc[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[mt][i] = DG ? 0.0f : bias_v[i >> 2][i & 3];
 
     // ---- 4 stages x 3 columns x 3 rows of taps.  One wave per SIMD: nothing else hides an LDS round
     // trip, so the A fragments of a column are requested TWO columns ahead and (forward pass behind a
     // ReLU) clamped one column ahead, in the shadow of the 12 MFMAs in between.
-    bf16x8v af[3][AROWS];
-    auto load_col = [&](int col, int set) {          // col = stage * 3 + dx
-      const int s = col / 3, dx = col - s * 3;
-#pragma unroll
-      for (int j = 0; j < AROWS; ++j)
-        af[set][j] = *reinterpret_cast<const bf16x8v*>(cur + s * IN_STAGE + a_addr[dx][j]);
-    };
+    auto load_col = [&](int col, int set) { load_col_from(cur, col, set); };
     auto relu_col = [&](int set) {
       if (RELU_IN) {
 #pragma unroll
         for (int j = 0; j < AROWS; ++j) af[set][j] = relu_frag(af[set][j], 0u);
       }
     };
-    load_col(0, 0);
-    load_col(1, 1);
-    relu_col(0);
+    relu_col(0);                                     // (columns 0 and 1 are on their way already)
+    if (diag & 4) {                                  // (timing knock-out: no MFMA loop)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt] = acc0;
+    }
     if (!(diag & 4))
 #pragma unroll
     for (int col = 0; col < NSTAGE * 3; ++col) {
@@ -314,7 +324,8 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgrou
       for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
-          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[s][dy * 3 + dx], af[col % 3][mt + dy], acc[mt], 0, 0, 0);
+          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[s][dy * 3 + dx], af[col % 3][mt + dy],
+                                                            (col == 0 && dy == 0) ? acc0 : acc[mt], 0, 0, 0);
       if (col + 1 < NSTAGE * 3) relu_col((col + 1) % 3);
       if (!DG || col < MT) deferred(col);              // the previous tile's epilogue, one chunk per column
       if (RELU_IN || !DG || col < MT) {                // 12 MFMAs with the packed max / epilogue VALU in their shadow
@@ -376,6 +387,11 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgrou
     if (NB == 2 && more) issue_tile(t + NB * tstride, cur);
 
     if (NB == 3 && more) issue_tile(t + NB * tstride, cur);      // forward form: the stores follow in the next tile's shadow
+    if (t + tstride < ntiles) {                                  // the next tile's first two A columns (it has landed)
+      const char* nxt = smem + ((slot + 1 == NB) ? 0 : slot + 1) * WsLds<DG>::BUF;
+      load_col_from(nxt, 0, 0);
+      load_col_from(nxt, 1, 1);
+    }
     // ---- rounding in line: acc -> packed bf16 words (ReLU after the rounding, on the packed words: a negative
     // bf16 is a negative int16; the bias already sits in the accumulators).  P[mt][0..3] = channel pairs (0,1)
     // of groups j, P[mt][4..7] = pairs (2,3): a lane holds channels nb + 8j + 4h + e of pixel (row mt, column r).
