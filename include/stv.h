@@ -245,6 +245,14 @@ int stv_image_to_u8(const float* x_nchw, uint8_t* out_hwc, int H, int W, const f
 int stv_loss_combine(const float* parts, const int32_t* table, const float* scale,
                      int n_terms, float style_w, float content_w, float* losses,
                      float* scores, void* stream);
+/* The same, and the producer also keeps the per-step history the reference's LossAccumulator keeps on the
+ * device (loss_accumulator.py:97-118: one ring slot per step): log_ring fp32 [3][log_capacity] (style, content,
+ * total), log_count = evaluations so far (device counter, advanced here), slot = count % capacity.  Saves the
+ * per-step copy kernel between two replays of the captured step.  log_ring and log_count both NULL: as above. */
+int stv_loss_combine_log(const float* parts, const int32_t* table, const float* scale,
+                         int n_terms, float style_w, float content_w, float* losses,
+                         float* scores, float* log_ring, int log_capacity, uint32_t* log_count,
+                         void* stream);
 
 /* ---- Optimizer updates (torch.optim.LBFGS.step / Adam.step driven from
  *      optimization.py:175), device resident: no host synchronisation. ----- */
@@ -300,7 +308,8 @@ enum { STV_LANE_SIDE = 1 << 29, STV_LANE_JOIN = 1 << 30 };
  * CONV with q1 set runs stv_conv_igemm_pool (q1 = pooled output, q2 = optional arg-max map); CONV with q2 AND q3 set runs
  * stv_conv_igemm_dual (q2 = x2, q3 = w2, n = cin2: inputs, despite the slot names).
  * GRAM_MULTI: p0 = HOST pointer to an array of stv_gram_tap_t, n = its length; the array is
- * copied into the program when it is created. */
+ * copied into the program when it is created.
+ * LOSS_COMBINE with q2 AND q3 set runs stv_loss_combine_log (q2 = log_ring, q3 = log_count, n = log_capacity). */
 typedef struct {
   int32_t op, dtype, flags, taps;
   int32_t H, W, cin, cout;

@@ -84,6 +84,8 @@ SIGNATURES = {
     "stv_content_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_void_p, c_int, c_int, c_void_p]),
     "stv_image_to_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_int, c_void_p]),
     "stv_loss_combine": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    "stv_loss_combine_log": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p,
+                                     c_int, c_void_p, c_void_p]),
     "stv_lbfgs_state_bytes": (c_size_t, [c_int]),
     "stv_lbfgs_workspace_bytes": (c_size_t, [c_size_t, c_int]),
     "stv_lbfgs_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_float, c_float, c_float, c_void_p]),

@@ -293,10 +293,13 @@ class _Engine:
             inline += after(node)
         return self.sched.forward_ops(x) + inline + tail
 
-    def _combine_op(self, style_w: float, content_w: float):
+    def _combine_op(self, style_w: float, content_w: float, score_log: tuple | None = None):
+        """``score_log`` = (ring fp32 [3, capacity], device counter int32 [1]): the combine kernel also appends
+        the three scores to the caller's history ring (stv_loss_combine_log)."""
+        ring, count = score_log if score_log is not None else (None, None)
         op = self.sched._op(op=plan.OP_LOSS_COMBINE, p0=self.parts, p1=self.table, p2=self.scale,
-                            q0=self.losses, q1=self.scores, cin=self.n_style + self.n_content,
-                            f0=style_w, f1=content_w)
+                            q0=self.losses, q1=self.scores, q2=ring, q3=count, n=ring.shape[1] if ring is not None else 0,
+                            cin=self.n_style + self.n_content, f0=style_w, f1=content_w)
         op.flags |= _lib.LANE_JOIN          # first reader of what the loss-side ops wrote
         return op
 
@@ -412,14 +415,16 @@ class _Engine:
         return t
 
     # -- execution -------------------------------------------------------------
-    def loss_and_grad(self, x: torch.Tensor, grad: torch.Tensor, style_w: float, content_w: float) -> None:
+    def loss_and_grad(self, x: torch.Tensor, grad: torch.Tensor, style_w: float, content_w: float, *,
+                      score_log: tuple | None = None) -> None:
         self.generation += 1
-        key = ("fused", x.data_ptr(), grad.data_ptr(), style_w, content_w)
+        key = ("fused", x.data_ptr(), grad.data_ptr(), style_w, content_w,
+               None if score_log is None else (score_log[0].data_ptr(), score_log[1].data_ptr(), tuple(score_log[0].shape)))
 
         def build():
             s = self.sched
             return (self._forward_with_losses(x, style_coef=style_w, with_seed=True)
-                    + [self._combine_op(style_w, content_w)]
+                    + [self._combine_op(style_w, content_w, score_log)]
                     + s.backward_ops(grad, style_coef=style_w, content_coef=content_w, coef_dev=None))
         self._program(key, build).run(self.use_graph)
 
@@ -563,6 +568,7 @@ class StyleContentModel(nn.Module):
         return style, content
 
     def loss_and_grad(self, x: torch.Tensor, style_w: float, content_w: float, *, live_scores: bool = False,
+                      score_log: tuple | None = None,
                       ) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """Fused step: writes d(style_w*S + content_w*C)/dx into ``x.grad``.
 
@@ -571,6 +577,8 @@ class StyleContentModel(nn.Module):
         Returns 0-d device tensors (style_score, content_score, total).  With
         ``live_scores`` they are views of the engine's score buffer - valid until the
         next evaluation, one copy kernel less per step (the runner consumes them at once).
+        ``score_log`` = (ring [3, capacity] fp32, counter [1] int32) on this device: the three scores are also
+        appended to that history ring by the combine kernel itself (LossAccumulator.device_log()).
         """
         self._require_targets()
         eng = self._engine_for(x)
@@ -582,7 +590,7 @@ class StyleContentModel(nn.Module):
         if grad is None or grad.shape != x.shape or grad.device != x.device:
             grad = torch.zeros_like(x, requires_grad=False)
             self._grad_buf = grad
-        eng.loss_and_grad(x.detach(), grad, float(style_w), float(content_w))
+        eng.loss_and_grad(x.detach(), grad, float(style_w), float(content_w), score_log=score_log)
         x.grad = grad
         scores = eng.scores if live_scores else eng.scores.clone()
         return scores[0], scores[1], scores[2]

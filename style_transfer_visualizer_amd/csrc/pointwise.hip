@@ -284,7 +284,9 @@ __global__ __launch_bounds__(1024) void loss_combine_kernel(const float* __restr
                                                             const int32_t* __restrict__ table,
                                                             const float* __restrict__ scale, int n_terms,
                                                             float style_w, float content_w,
-                                                            float* __restrict__ losses, float* __restrict__ scores) {
+                                                            float* __restrict__ losses, float* __restrict__ scores,
+                                                            float* __restrict__ log_ring, int log_cap,
+                                                            uint32_t* __restrict__ log_count) {
   constexpr int MAXT = 64, NW = 16;
   __shared__ int s_off[MAXT], s_cnt[MAXT], s_kind[MAXT], s_start[MAXT + 1];
   __shared__ float s_scale[MAXT], s_term[MAXT];
@@ -347,6 +349,14 @@ __global__ __launch_bounds__(1024) void loss_combine_kernel(const float* __restr
     scores[1] = content;
     scores[2] = total_loss;
     scores[3] = (isfinite(style) && isfinite(content) && isfinite(total_loss)) ? 1.0f : 0.0f;
+    if (log_ring) {          // per-evaluation history kept by the producer: slot = evaluations so far (mod capacity)
+      const uint32_t k = *log_count;
+      const uint32_t slot = k % (uint32_t)log_cap;
+      log_ring[slot] = style;
+      log_ring[(size_t)log_cap + slot] = content;
+      log_ring[2 * (size_t)log_cap + slot] = total_loss;
+      *log_count = k + 1;
+    }
   }
 }
 
@@ -522,14 +532,21 @@ extern "C" int stv_content_grad(const void* F, const void* target, void* dF, siz
   return STV_OK;
 }
 
-extern "C" int stv_loss_combine(const float* parts, const int32_t* table, const float* scale, int n_terms,
-                                float style_w, float content_w, float* losses, float* scores, void* stream) {
+extern "C" int stv_loss_combine_log(const float* parts, const int32_t* table, const float* scale, int n_terms,
+                                    float style_w, float content_w, float* losses, float* scores, float* log_ring,
+                                    int log_capacity, uint32_t* log_count, void* stream) {
   if (!parts || !table || !scale || !losses || !scores || n_terms < 0) return STV_ERR_ARG;
   if (n_terms > 64) return STV_ERR_ARG;
+  if ((log_ring == nullptr) != (log_count == nullptr) || (log_ring && log_capacity <= 0)) return STV_ERR_ARG;
   hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), parts,
-                     table, scale, n_terms, style_w, content_w, losses, scores);
+                     table, scale, n_terms, style_w, content_w, losses, scores, log_ring, log_capacity, log_count);
   STV_CHECK_LAUNCH();
   return STV_OK;
+}
+
+extern "C" int stv_loss_combine(const float* parts, const int32_t* table, const float* scale, int n_terms,
+                                float style_w, float content_w, float* losses, float* scores, void* stream) {
+  return stv_loss_combine_log(parts, table, scale, n_terms, style_w, content_w, losses, scores, nullptr, 0, nullptr, stream);
 }
 
 extern "C" int stv_image_to_u8(const float* x_nchw, uint8_t* out_hwc, int H, int W, const float* mean3,

@@ -46,6 +46,18 @@ class LossAccumulator:
         self._records = 0         # records ever written
         self._pending: tuple[int, torch.Tensor] | None = None
         self._last: LoggedLoss | None = None
+        self._counter: torch.Tensor | None = None      # device-side record count, once a producer logs for us
+
+    def device_log(self) -> tuple[torch.Tensor, torch.Tensor] | None:
+        """(ring [3, capacity] fp32, counter [1] int32) for a producer that appends each step's scores to the
+        history itself (``stv_loss_combine_log``: slot = counter % capacity, counter += 1) - the per-step copy
+        kernel then disappears from the step.  None when there is no fp32 device ring to share.  Records that
+        still arrive through :meth:`accumulate` without ``logged_by_producer`` keep the counter in step."""
+        if not self._track or self._ring is None or self._ring.dtype != torch.float32 or not self._ring.is_cuda:
+            return None
+        if self._counter is None:
+            self._counter = torch.full((1,), self._records, dtype=torch.int32, device=self._ring.device)
+        return self._ring, self._counter
 
     @property
     def capacity(self) -> int:
@@ -63,8 +75,10 @@ class LossAccumulator:
         return self._records > self._capacity
 
     def accumulate(self, step_idx: int, style_loss: torch.Tensor, content_loss: torch.Tensor,
-                   total_loss: torch.Tensor, *, force: bool = False) -> LoggedLoss | None:
-        """Record one step; return host scalars only at the logging cadence."""
+                   total_loss: torch.Tensor, *, force: bool = False, logged_by_producer: bool = False,
+                   ) -> LoggedLoss | None:
+        """Record one step; return host scalars only at the logging cadence.  ``logged_by_producer``: the
+        evaluation that produced these scores already appended them to the ring (:meth:`device_log`)."""
         triple = self._adjacent(style_loss, content_loss, total_loss)
         if triple is None:
             triple = torch.stack((style_loss.detach().reshape(()), content_loss.detach().reshape(()),
@@ -74,7 +88,10 @@ class LossAccumulator:
             if self._ring is None:
                 msg = "History buffers are uninitialized."
                 raise RuntimeError(msg)
-            self._ring[:, self._next] = triple.to(dtype=self._buffer_dtype, device=self._device)
+            if not (logged_by_producer and self._counter is not None):
+                self._ring[:, self._next] = triple.to(dtype=self._buffer_dtype, device=self._device)
+                if self._counter is not None:
+                    self._counter += 1
             self._next = (self._next + 1) % self._capacity
             self._count = min(self._count + 1, self._capacity)
             self._records += 1

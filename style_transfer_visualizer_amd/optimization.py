@@ -33,7 +33,7 @@ from .constants import CSV_LOGGING_RECOMMENDED_STEPS
 from .logging_utils import logger
 from .loss_accumulator import DEFAULT_HISTORY_CAPACITY, LoggedLoss, LossAccumulator
 from .loss_logger import LossCSVLogger
-from .optimizers import make_lbfgs
+from .optimizers import HipAdam, HipLBFGS, make_lbfgs
 from .type_defs import LossHistory
 
 
@@ -146,6 +146,11 @@ class OptimizationRunner:
         self._closure_calls = 0
         self._fused = callable(getattr(model, "loss_and_grad", None))
         self._live_scores: bool | None = None
+        self._model_kwargs: frozenset[str] = frozenset()
+        # optimizers that evaluate the closure exactly once per step: the model may then keep the loss history
+        # itself (one ring slot per evaluation, written by the kernel that combines the scores)
+        self._single_eval = isinstance(self.optimizer, (HipLBFGS, HipAdam))
+        self._producer_logged = False
 
     # ------------------------------------------------------------------ properties
     @property
@@ -282,12 +287,19 @@ class OptimizationRunner:
         if self._live_scores is None:
             import inspect
             try:
-                self._live_scores = "live_scores" in inspect.signature(self.model.loss_and_grad).parameters
+                self._model_kwargs = frozenset(inspect.signature(self.model.loss_and_grad).parameters)
             except (TypeError, ValueError):
-                self._live_scores = False
+                self._model_kwargs = frozenset()
+            self._live_scores = "live_scores" in self._model_kwargs
+        kwargs = {}
         if self._live_scores:
-            return self.model.loss_and_grad(self.input_img, style_w, content_w, live_scores=True)
-        return self.model.loss_and_grad(self.input_img, style_w, content_w)
+            kwargs["live_scores"] = True
+        if self._single_eval and "score_log" in self._model_kwargs and self._loss_accumulator is not None:
+            log = self._loss_accumulator.device_log()
+            if log is not None:
+                kwargs["score_log"] = log
+                self._producer_logged = True
+        return self.model.loss_and_grad(self.input_img, style_w, content_w, **kwargs)
 
     def _final_loss_tensor(self) -> torch.Tensor:
         if self._last_loss_tensor is not None:
@@ -314,8 +326,9 @@ class OptimizationRunner:
     def _record_losses(self, tensors: StepTensors) -> LoggedLoss | None:
         if self._loss_accumulator is None:
             return None
+        by_producer, self._producer_logged = self._producer_logged, False
         logged = self._loss_accumulator.accumulate(
-            tensors.step, tensors.style_score, tensors.content_score, tensors.total_loss)
+            tensors.step, tensors.style_score, tensors.content_score, tensors.total_loss, logged_by_producer=by_producer)
         if logged is not None and self.loss_logger is not None:
             self.loss_logger.log(logged.step, logged.style_loss, logged.content_loss, logged.total_loss)
         return logged

@@ -198,6 +198,51 @@ def test_frames_from_the_hip_model_cadence_and_values(steps, save_every, monkeyp
         assert np.array_equal(frame, _ref_frame(x_then, oc.normalize)), f"frame of step {step}"
 
 
+# ------------------------------------------------ loss history kept by the combine kernel itself
+@pytest.mark.parametrize("bf16", [False, True])
+def test_producer_logged_history_changes_nothing(bf16, monkeypatch):
+    """The combine kernel appends each step's scores to the LossAccumulator's ring itself
+    (stv_loss_combine_log) instead of one copy kernel per step: image and exported loss history are
+    BIT-identical to the run with the feature off, also once the ring has wrapped around."""
+    from style_transfer_visualizer_amd import loss_accumulator
+    from style_transfer_visualizer_amd.loss_accumulator import LossAccumulator
+    case = GoldenCase("mini_white_lbfgs")
+    weights = case.weights()
+    steps = 9
+    results = {}
+    for mode in ("copy", "producer"):
+        with monkeypatch.context() as mp:
+            mp.setattr(core_model, "initialize_vgg", lambda: core_model.build_vgg_features(weights, case.cfg).eval())
+            mp.setattr(loss_accumulator, "DEFAULT_HISTORY_CAPACITY", 6)       # the ring wraps after six records
+            mp.setattr(optimization, "DEFAULT_HISTORY_CAPACITY", 6)
+            handed = []
+            if mode == "copy":
+                mp.setattr(LossAccumulator, "device_log", lambda self: None)
+            else:
+                orig = LossAccumulator.device_log
+
+                def spy(self, orig=orig, handed=handed):
+                    log = orig(self)
+                    handed.append(log is not None)
+                    return log
+                mp.setattr(LossAccumulator, "device_log", spy)
+            cfg = stv_config.StyleTransferConfig.model_validate({})
+            oc = cfg.optimization
+            oc.steps, oc.init_method, oc.seed = steps, "content", 0
+            oc.style_layers, oc.content_layers = list(case.meta["style_layers"]), list(case.meta["content_layers"])
+            cfg.video.create_video = False
+            content, style = case.images()
+            model, x, opt = core_model.prepare_model_and_input(content.to(DEV), style.to(DEV), DEV, oc,
+                                                               precision="bf16" if bf16 else "fp32")
+            runner = optimization.OptimizationRunner(model, x, cfg, optimizer=opt, progress_bar=_Bar())
+            _, history, _ = runner.run()
+            results[mode] = (x.detach().clone(), history, handed)
+    assert results["producer"][2] == [True] * steps
+    assert torch.equal(results["copy"][0], results["producer"][0])
+    assert results["copy"][1] == results["producer"][1]
+    assert len(results["producer"][1]["total_loss"]) == 6       # the last six of nine steps
+
+
 # ------------------------------------------------------------------ input checks of the HIP model
 def test_input_channel_count_and_stale_backward_are_rejected(monkeypatch):
     case = GoldenCase("mini_white_lbfgs")
