@@ -222,6 +222,11 @@ int stv_gram_multi(const stv_gram_tap_t* taps, int n_taps, int dtype, void* stre
 #define STV_CONTENT_LOSS_PARTS 256
 int stv_content_loss(const void* F, const void* target, float* loss_part, size_t n,
                      int dtype, void* stream);
+/* Both at once for a step whose coefficient is known up front (the fused step: reference optimization.py:298-313
+ * with content_w folded in): the loss partials exactly as stv_content_loss leaves them, and dF = coef*(2/n)*(F - target)
+ * WRITTEN - the dgrad that later produces this layer's gradient accumulates onto it (STV_ACCUM). */
+int stv_content_loss_grad(const void* F, const void* target, float* loss_part, void* dF, size_t n,
+                          float coef, int dtype, void* stream);
 /* dF (=|+=) coef*(*coef_dev)*(2/n)*(F - target) */
 int stv_content_grad(const void* F, const void* target, void* dF, size_t n, float coef,
                      const float* coef_dev, int flags, int dtype, void* stream);
@@ -309,6 +314,7 @@ enum { STV_LANE_SIDE = 1 << 29, STV_LANE_JOIN = 1 << 30 };
  * stv_conv_igemm_dual (q2 = x2, q3 = w2, n = cin2: inputs, despite the slot names).
  * GRAM_MULTI: p0 = HOST pointer to an array of stv_gram_tap_t, n = its length; the array is
  * copied into the program when it is created.
+ * CONTENT_LOSS with q1 set runs stv_content_loss_grad (q1 = dF, f0 = coef).
  * LOSS_COMBINE with q2 AND q3 set runs stv_loss_combine_log (q2 = log_ring, q3 = log_count, n = log_capacity). */
 typedef struct {
   int32_t op, dtype, flags, taps;

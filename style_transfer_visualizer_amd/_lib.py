@@ -81,6 +81,7 @@ SIGNATURES = {
     "stv_gram_finish": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_void_p, c_int, c_void_p]),
     "stv_gram_multi": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "stv_content_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "stv_content_loss_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_int, c_void_p]),
     "stv_content_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_void_p, c_int, c_int, c_void_p]),
     "stv_image_to_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_int, c_void_p]),
     "stv_loss_combine": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]),

@@ -231,7 +231,8 @@ class _Engine:
         self._stage: torch.Tensor | None = None      # fp32 contiguous copy of a non-conforming input
 
     # -- op list pieces -------------------------------------------------------
-    def _tap_loss_ops(self, tap, *, style_coef: float, coef_dev: torch.Tensor | None, with_seed: bool) -> list:
+    def _tap_loss_ops(self, tap, *, style_coef: float, coef_dev: torch.Tensor | None, with_seed: bool,
+                      content_coef: float | None = None) -> list:
         """Loss-side ops of one tap.  They are spliced in right after the op that produces the tapped
         activation, while it is still L2 / Infinity-Cache resident.  STV_SIDE_LANE=1 flags them for
         the executor's second stream (fork after the tapped conv, join at the score combine); measured
@@ -242,6 +243,10 @@ class _Engine:
             cd = coef_dev[tap.order:] if coef_dev is not None else None
             ops_ = s.gram_ops(tap, gram_out=None, target=tap.target, loss_part=self.parts[tap.parts_off:],
                               sgrad=tap.sgrad if with_seed else None, coef=style_coef, coef_dev=cd)
+        elif content_coef is not None and self._content_fused(tap):
+            # loss and gradient of the content term in one pass (the coefficient is known: the fused step)
+            ops_ = [s._op(op=plan.OP_CONTENT_LOSS, p0=tap.buf.act, p1=tap.target, q0=self.parts[tap.parts_off:],
+                          q1=tap.buf.grad, n=tap.buf.act.numel(), f0=content_coef)]
         else:
             ops_ = [s._op(op=plan.OP_CONTENT_LOSS, p0=tap.buf.act, p1=tap.target,
                           q0=self.parts[tap.parts_off:], n=tap.buf.act.numel())]
@@ -252,7 +257,13 @@ class _Engine:
                 o.flags |= _lib.LANE_SIDE
         return ops_
 
-    def _forward_with_losses(self, x: torch.Tensor, *, style_coef: float, with_seed: bool) -> list:
+    def _content_fused(self, tap) -> bool:
+        """One content tap per buffer, nothing else writing that buffer's gradient first (A/B: STV_FUSE_CONTENT=0)."""
+        return (os.environ.get("STV_FUSE_CONTENT", "1") != "0" and tap.buf.grad is not None
+                and sum(1 for t in tap.buf.taps if t.kind == "content") == 1)
+
+    def _forward_with_losses(self, x: torch.Tensor, *, style_coef: float, with_seed: bool,
+                             content_coef: float | None = None) -> list:
         # Batched loss side: the Gram chain of a tap is a handful of latency-bound launches (partial
         # sums, finish), and side by side in one grid (stv_gram_multi) several taps cost the slowest
         # instead of the sum.  Deferring a tap to the end of the forward pass only pays while its
@@ -276,7 +287,8 @@ class _Engine:
             tail.append(s.gram_multi_op(specs))
         if deferred and len(deferred) == len(s.style_taps):
             for tap in s.content_taps:
-                tail += self._tap_loss_ops(tap, style_coef=style_coef, coef_dev=None, with_seed=with_seed)
+                tail += self._tap_loss_ops(tap, style_coef=style_coef, coef_dev=None, with_seed=with_seed,
+                                           content_coef=content_coef)
             return s.forward_ops(x) + tail
         held = {id(tap) for tap in deferred}
 
@@ -284,7 +296,8 @@ class _Engine:
             out = []
             for tap in node.dst.taps:
                 if id(tap) not in held:
-                    out += self._tap_loss_ops(tap, style_coef=style_coef, coef_dev=None, with_seed=with_seed)
+                    out += self._tap_loss_ops(tap, style_coef=style_coef, coef_dev=None, with_seed=with_seed,
+                                              content_coef=content_coef)
             return out
         if os.environ.get("STV_LOSS_INTERLEAVE", "1") == "1":
             return self.sched.forward_ops(x, after_node=after) + tail
@@ -423,9 +436,12 @@ class _Engine:
 
         def build():
             s = self.sched
-            return (self._forward_with_losses(x, style_coef=style_w, with_seed=True)
+            s.alloc_grads()          # the content term's gradient is written during the forward half
+            fused_content = tuple(t for t in s.content_taps if self._content_fused(t))
+            return (self._forward_with_losses(x, style_coef=style_w, with_seed=True, content_coef=content_w)
                     + [self._combine_op(style_w, content_w, score_log)]
-                    + s.backward_ops(grad, style_coef=style_w, content_coef=content_w, coef_dev=None))
+                    + s.backward_ops(grad, style_coef=style_w, content_coef=content_w, coef_dev=None,
+                                     prewritten=fused_content))
         self._program(key, build).run(self.use_graph)
 
     def forward_losses(self, x: torch.Tensor) -> None:

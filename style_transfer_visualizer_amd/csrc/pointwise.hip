@@ -252,6 +252,38 @@ __global__ __launch_bounds__(256) void content_loss_kernel(const T* __restrict__
   s = block_sum_256(s, red);
   if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
+// Loss and gradient of the content term in one pass over (F, target): the same partial sums in the same
+// order as content_loss_kernel (same grid, same stride), and dF = coef * 2/n * (F - target) WRITTEN (the dgrad
+// that produces this layer's gradient later accumulates onto it) - one read of the two maps instead of two.
+template <typename T>
+__global__ __launch_bounds__(256) void content_loss_grad_kernel(const T* __restrict__ f, const T* __restrict__ t,
+                                                                float* __restrict__ part, T* __restrict__ df, size_t n,
+                                                                float coef) {
+  constexpr int kVec = elem_traits<T>::kVec;
+  __shared__ float red[4];
+  const float k = coef * (2.0f / (float)n);
+  float s = 0.0f;
+  const size_t nv = n / kVec;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
+    float a[kVec], b[kVec], o[kVec];
+    unpack16<T>(reinterpret_cast<const u32x4*>(f)[i], a);
+    unpack16<T>(reinterpret_cast<const u32x4*>(t)[i], b);
+#pragma unroll
+    for (int e = 0; e < kVec; ++e) {
+      const float d = a[e] - b[e];
+      s = fmaf(d, d, s);
+      o[e] = k * d;
+    }
+    reinterpret_cast<u32x4*>(df)[i] = pack16<T>(o);
+  }
+  for (size_t i = nv * kVec + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float d = elem_traits<T>::load(f + i) - elem_traits<T>::load(t + i);
+    s = fmaf(d, d, s);
+    elem_traits<T>::store(df + i, k * d);
+  }
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
 template <typename T>
 __global__ __launch_bounds__(256) void content_grad_kernel(const T* __restrict__ f, const T* __restrict__ t,
                                                            T* __restrict__ df, size_t n, float coef,
@@ -509,6 +541,21 @@ extern "C" int stv_content_loss(const void* F, const void* target, float* loss_p
   else if (dtype == STV_BF16)
     hipLaunchKernelGGL(content_loss_kernel<bf16_t>, dim3(STV_CONTENT_LOSS_PARTS), dim3(256), 0, st,
                        static_cast<const bf16_t*>(F), static_cast<const bf16_t*>(target), loss_part, n);
+  else
+    return STV_ERR_ARG;
+  STV_CHECK_LAUNCH();
+  return STV_OK;
+}
+extern "C" int stv_content_loss_grad(const void* F, const void* target, float* loss_part, void* dF, size_t n, float coef,
+                                     int dtype, void* stream) {
+  if (!F || !target || !loss_part || !dF || n == 0) return STV_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == STV_F32)
+    hipLaunchKernelGGL(content_loss_grad_kernel<float>, dim3(STV_CONTENT_LOSS_PARTS), dim3(256), 0, st,
+                       static_cast<const float*>(F), static_cast<const float*>(target), loss_part, static_cast<float*>(dF), n, coef);
+  else if (dtype == STV_BF16)
+    hipLaunchKernelGGL(content_loss_grad_kernel<bf16_t>, dim3(STV_CONTENT_LOSS_PARTS), dim3(256), 0, st,
+                       static_cast<const bf16_t*>(F), static_cast<const bf16_t*>(target), loss_part, static_cast<bf16_t*>(dF), n, coef);
   else
     return STV_ERR_ARG;
   STV_CHECK_LAUNCH();

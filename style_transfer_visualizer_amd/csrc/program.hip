@@ -69,6 +69,8 @@ int run_op(const stv_op_t& op, void* st) {
                              static_cast<float*>(o.q0), static_cast<float*>(o.q1), o.q2, (int)o.n, o.cin,
                              o.f0, o.f1, o.f2, static_cast<const float*>(o.p2), o.dtype, st);
     case STV_OP_CONTENT_LOSS:
+      if (o.q1)   // loss + gradient in one pass (q1 = dF written, f0 = coefficient)
+        return stv_content_loss_grad(o.p0, o.p1, static_cast<float*>(o.q0), o.q1, (size_t)o.n, o.f0, o.dtype, st);
       return stv_content_loss(o.p0, o.p1, static_cast<float*>(o.q0), (size_t)o.n, o.dtype, st);
     case STV_OP_CONTENT_GRAD:
       return stv_content_grad(o.p0, o.p1, o.q0, (size_t)o.n, o.f0, static_cast<const float*>(o.p2), o.flags,

@@ -367,6 +367,13 @@ def content_loss(F: torch.Tensor, target: torch.Tensor, loss_part: torch.Tensor)
                                     _stream()), "stv_content_loss")
 
 
+def content_loss_grad(F: torch.Tensor, target: torch.Tensor, loss_part: torch.Tensor, dF: torch.Tensor, coef: float) -> None:
+    """Loss partials (as :func:`content_loss`) and ``dF = coef * 2/n * (F - target)`` (written) in one pass."""
+    lib = _lib.load()
+    _lib.check(lib.stv_content_loss_grad(_ptr(F), _ptr(target), _ptr(loss_part), _ptr(dF), F.numel(), coef,
+                                         dtype_code(F.dtype), _stream()), "stv_content_loss_grad")
+
+
 def content_grad(F: torch.Tensor, target: torch.Tensor, dF: torch.Tensor, coef: float,
                  coef_dev: torch.Tensor | None = None, flags: int = 0) -> None:
     lib = _lib.load()

@@ -327,12 +327,15 @@ class Schedule:
                 nd.dst.grad = torch.zeros_like(nd.dst.act) if self.halo else torch.empty_like(nd.dst.act)
 
     def backward_ops(self, x_grad: torch.Tensor, *, style_coef: float, content_coef: float,
-                     coef_dev: torch.Tensor | None) -> list[StvOp]:
+                     coef_dev: torch.Tensor | None, prewritten: tuple = ()) -> list[StvOp]:
         """Reverse schedule.  ``coef_dev`` (optional fp32 device vector, style terms
-        first) holds upstream d(total)/d(loss_k) for the autograd path."""
+        first) holds upstream d(total)/d(loss_k) for the autograd path.  ``prewritten``: content taps whose
+        gradient the forward half already WROTE into their buffer's ``grad`` (stv_content_loss_grad): no
+        content-gradient pass for them, and whatever produces that gradient next accumulates onto it."""
         self.alloc_grads()
         out: list[StvOp] = []
-        written: set[int] = set()
+        pre = {id(t) for t in prewritten}
+        written: set[int] = {id(t.buf) for t in prewritten}
 
         def acc_flag(buf: Buf) -> int:
             return ACCUM if id(buf) in written else 0
@@ -348,7 +351,7 @@ class Schedule:
             if id(nd) in routed:         # its consumer's dgrad already wrote nd.src.grad
                 continue
             for tap in d.taps:
-                if id(tap) in fused_taps:
+                if id(tap) in fused_taps or id(tap) in pre:
                     continue
                 if tap.kind == "style":
                     if d.act.is_cuda:

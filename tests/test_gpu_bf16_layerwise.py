@@ -147,6 +147,10 @@ def test_bf16_every_stored_tensor_within_one_ulp_of_the_oracle_op(size, monkeypa
         relu_mask_by_consumer = consumer is not None and (consumer.relu_in or (b.relu_fused and not b.taps))
         fused_tap = None
         g = None
+        # content taps whose gradient the forward half already wrote (stv_content_loss_grad): rounded first, and
+        # whatever produces this buffer's gradient accumulates onto the rounded value
+        pre = [t for t in b.taps if t.kind == "content" and eng._content_fused(t)]
+        pre_sum = sum((_bf(tap_term(t)) for t in pre), torch.zeros(())) if pre else None
         if consumer is not None:
             dy = _nchw(consumer.dst.grad)
             if consumer.kind == "conv":
@@ -157,6 +161,8 @@ def test_bf16_every_stored_tensor_within_one_ulp_of_the_oracle_op(size, monkeypa
                 fused_tap = next((t for t in b.taps if t.kind == "style" and (b.H, b.W, b.C) in dual), None)
                 if fused_tap is not None:
                     base = base + tap_term(fused_tap)
+                if pre:
+                    base = base + pre_sum
                 g = _bf(base)
             elif consumer.kind == "pool":
                 if routed:                    # pooled gradient = bf16(dgrad of the conv behind the pool), then routed
@@ -169,8 +175,12 @@ def test_bf16_every_stored_tensor_within_one_ulp_of_the_oracle_op(size, monkeypa
                     g = g * (act > 0)
             else:
                 g = dy * (act > 0)
+            if pre and consumer.kind != "conv":
+                g = _bf(g + pre_sum)
+        elif pre:
+            g = pre_sum
         for tap in b.taps:
-            if tap is fused_tap:
+            if tap is fused_tap or any(tap is t for t in pre):
                 continue
             term = tap_term(tap)
             g = _bf(term) if g is None else _bf(g + term)

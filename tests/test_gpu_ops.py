@@ -491,6 +491,13 @@ def test_content_loss_and_grad(dtype):
     out = prev.to(dtype).to(DEV)
     ops.content_grad(fd, td, out, 3.0, flags=ops.ACCUM)
     assert_close(out, fr.grad + prev, dtype, 1, "content grad")
+    # both in one pass (stv_content_loss_grad): the same partial sums, the same (written) gradient, bit for bit
+    parts2 = torch.zeros(256, device=DEV)
+    g_one = torch.full_like(fd, float("nan"))
+    ops.content_loss_grad(fd, td, parts2, g_one, 3.0)
+    g_two = torch.empty_like(fd)
+    ops.content_grad(fd, td, g_two, 3.0)
+    assert torch.equal(parts2, parts) and torch.equal(g_one, g_two)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
