@@ -104,7 +104,7 @@ struct Cfg {
   static constexpr int LDS_BYTES = (KS == 1 || RING_BYTES > C_BYTES) ? RING_BYTES : C_BYTES;
   static_assert(NWAVES * KS == 4 || NWAVES * KS == 8, "4 or 8 waves per workgroup");
   static_assert(KS == 1 || KS == 2, "K split");
-  static_assert(NBUF == 2 || NBUF == 3, "ring depth");
+  static_assert(NBUF >= 2 && NBUF <= 6, "ring depth");
   static_assert(TH % WM == 0 && BN % (WN * 32) == 0, "tile split");
   static_assert(BN % 16 == 0, "swizzle period");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -292,35 +292,24 @@ __device__ __forceinline__ void conv_mainloop(const Phase<typename C::Elem>& ph,
   };
 
   // prologue: rounds 0 .. NBUF-2 in flight, round 0 landed
-  char* const buf0 = ring;
-  char* const buf1 = ring + C::STAGE_BYTES;
-  char* const buf2 = ring + (C::NBUF - 1) * C::STAGE_BYTES;       // only used when NBUF == 3
 #pragma unroll
-  for (int k = 0; k < C::PPW; ++k) dma(k, 0, buf0);
-  if (C::NBUF == 3) {
+  for (int rnd = 0; rnd + 1 < C::NBUF; ++rnd)
 #pragma unroll
-    for (int k = 0; k < C::PPW; ++k) dma(k, 1, buf1);
-  }
+    for (int k = 0; k < C::PPW; ++k) dma(k, rnd, ring + rnd * C::STAGE_BYTES);
   wait_vmcnt<(C::NBUF - 2) * C::PPW>();
   __builtin_amdgcn_s_barrier();
   STV_STAMP(1);
 
+  // round c is computed out of ring slot c % NBUF while round c + NBUF - 1 streams into the slot before it
   int c = 0;
-  if (C::NBUF == 3) {
-    for (; c + 2 < nrounds; c += 3) {
-      run_stage(buf0, buf2, c);
-      run_stage(buf1, buf0, c + 1);
-      run_stage(buf2, buf1, c + 2);
-    }
-    if (c < nrounds) run_stage(buf0, buf2, c);
-    if (c + 1 < nrounds) run_stage(buf1, buf0, c + 1);
-  } else {
-    for (; c + 1 < nrounds; c += 2) {
-      run_stage(buf0, buf1, c);
-      run_stage(buf1, buf0, c + 1);
-    }
-    if (c < nrounds) run_stage(buf0, buf1, c);
+  for (; c + C::NBUF <= nrounds; c += C::NBUF) {
+#pragma unroll
+    for (int k = 0; k < C::NBUF; ++k)
+      run_stage(ring + k * C::STAGE_BYTES, ring + ((k + C::NBUF - 1) % C::NBUF) * C::STAGE_BYTES, c + k);
   }
+#pragma unroll
+  for (int k = 0; k + 1 < C::NBUF; ++k)
+    if (c + k < nrounds) run_stage(ring + k * C::STAGE_BYTES, ring + ((k + C::NBUF - 1) % C::NBUF) * C::STAGE_BYTES, c + k);
   // the zero-fill DMAs of the rounds past the end still target the ring: drain them before the
   // C tile takes over the same LDS
   wait_vmcnt<0>();
