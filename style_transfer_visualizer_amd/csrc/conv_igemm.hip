@@ -58,6 +58,10 @@ __device__ unsigned long long g_stv_stamps[8 * 16384];
 #define STV_DIAG 0
 #endif
 
+#ifndef STV_STORE_AUX
+#define STV_STORE_AUX 0      // cache-policy bits of the output stores (diagnostic builds: 2 = nt, 16 = sc1)
+#endif
+
 namespace {
 
 template <typename T, int TH_, int BN_, int WM_, int WN_, int TAPS_, int KS_ = 1, int NBUF_ = 3>
@@ -576,10 +580,10 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
                   }
                   const u32x4 v = {out[0] & keep[0], out[1] & keep[1], out[2] & keep[2], out[3] & keep[3]};
                   const uint32_t o2 = off != kOob ? base + (uint32_t)((((pos >> 1) * 2 * a.W + (pos & 1)) * a.cout) * 2) : kOob;
-                  __builtin_amdgcn_raw_buffer_store_b128(v, rs_route, o2, 0, 0);
+                  __builtin_amdgcn_raw_buffer_store_b128(v, rs_route, o2, 0, STV_STORE_AUX);
                 }
               } else {
-                __builtin_amdgcn_raw_buffer_store_b128(out, rs_out, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(out, rs_out, off, 0, STV_STORE_AUX);
               }
             }
           }

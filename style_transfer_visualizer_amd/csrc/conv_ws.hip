@@ -30,6 +30,10 @@
 #include "stv_common.h"
 #include "conv_args.h"
 
+#ifndef STV_STORE_AUX
+#define STV_STORE_AUX 0      // cache-policy bits of the output stores (diagnostic builds: 2 = nt, 16 = sc1)
+#endif
+
 namespace {
 
 constexpr int TH = 8, TW = 32;                     // workgroup tile: 8 rows x 32 pixels
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgrou
       const u32x4 out = {sx[0], sy[0], sx[1], sy[1]};
       const int nn = nb + 8 * jp + 8 * h;
       const uint32_t off = (poff != kOob && !(diag & 1)) ? poff + (uint32_t)(nn * 2) : kOob;
-      __builtin_amdgcn_raw_buffer_store_b128(out, rs_out, off, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(out, rs_out, off, 0, STV_STORE_AUX);
     }
   };
   auto right = [](uint32_t v) -> uint32_t {      // the neighbouring lane's word (quad_perm [1,0,3,2])
