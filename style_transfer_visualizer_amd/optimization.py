@@ -292,6 +292,7 @@ class OptimizationRunner:
                 self._model_kwargs = frozenset()
             self._live_scores = "live_scores" in self._model_kwargs
         kwargs = {}
+        self._producer_logged = False
         if self._live_scores:
             kwargs["live_scores"] = True
         if self._single_eval and "score_log" in self._model_kwargs and self._loss_accumulator is not None:

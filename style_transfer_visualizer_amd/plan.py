@@ -265,7 +265,8 @@ class Schedule:
                         tap.partials = torch.empty(ops.gram_ksplit(d.H * d.W, d.C), d.C, d.C, device=self.device,
                                                    dtype=torch.float32)
                     slabs = tap.partials
-                    tap.partials_fused = True
+                if tap is not None:
+                    tap.partials_fused = slabs is not None      # (re-decided per build: the switch may have changed)
                 out.append(self._op(op=OP_CONV_FIRST_FWD, p0=x, p1=nd.wf, p2=nd.bias, p3=nd.wb, q0=d.act, q1=slabs,
                                     H=d.H, W=d.W, cin=nd.cin, cout=d.C))
             elif nd.kind == "conv":
