@@ -91,10 +91,15 @@ __device__ __forceinline__ float dot4(const f32x4& a, const f32x4& b) {
 // ---- pass A ---------------------------------------------------------------------------------
 template <int U>
 __global__ __launch_bounds__(256) void pass_a_kernel(const float* __restrict__ g, const CState* st, CWs w,
-                                                     size_t n, size_t nn, int hist, int nparts) {
+                                                     size_t n, size_t nn, int hist, int nparts, int ntiles, int pgroups) {
+  // blockIdx.x = pair group * ntiles + tile.  A small image has too few tiles to keep enough loads in flight
+  // (256^2: 192 workgroups walking 100 pairs one after the other ran at 2.3 TB/s), so the PAIRS of a tile are
+  // dealt to `pgroups` workgroups; every (pair, tile, wave) partial still has exactly one writer, and the
+  // scalars / the new pair's own vectors belong to group 0.
   const int S = hist + 1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const size_t base = (size_t)blockIdx.x * (256 * 4 * U);
+  const int tile_idx = (int)blockIdx.x % ntiles, pgrp = (int)blockIdx.x / ntiles;
+  const size_t base = (size_t)tile_idx * (256 * 4 * U);
   const float t = st->t;
   const int m = st->hist_len, head = st->head;
   const int cslot = (head + m) % S;
@@ -115,16 +120,20 @@ __global__ __launch_bounds__(256) void pass_a_kernel(const float* __restrict__ g
       gmax = fmaxf(gmax, fabsf(gv[u][e]));
       gl1 += fabsf(gv[u][e]);
     }
-    *reinterpret_cast<f32x4*>(yc + idx) = yv[u];
-    *reinterpret_cast<f32x4*>(sc + idx) = sv[u];
+    if (pgrp == 0) {
+      *reinterpret_cast<f32x4*>(yc + idx) = yv[u];
+      *reinterpret_cast<f32x4*>(sc + idx) = sv[u];
+    }
     gg += dot4(gv[u], gv[u]);
     gs += dot4(gv[u], sv[u]);
     gy += dot4(gv[u], yv[u]);
     sy += dot4(sv[u], yv[u]);
     yy += dot4(yv[u], yv[u]);
   }
-  const int p = blockIdx.x * 4 + wave;
-  for (int jj = 0; jj < m; ++jj) {
+  const int p = tile_idx * 4 + wave;
+  const int per = (m + pgroups - 1) / pgroups;
+  const int j_end = (pgrp + 1) * per < m ? (pgrp + 1) * per : m;
+  for (int jj = pgrp * per; jj < j_end; ++jj) {
     const int slot = (head + jj) % S;
     const float* __restrict__ sj = w.S + (size_t)slot * nn;
     const float* __restrict__ yj = w.Y + (size_t)slot * nn;
@@ -156,6 +165,7 @@ __global__ __launch_bounds__(256) void pass_a_kernel(const float* __restrict__ g
       o[(size_t)4 * nparts] = a4;
     }
   }
+  if (pgrp != 0) return;
   gmax = wave_max(gmax);
   gl1 = wave_sum(gl1); gg = wave_sum(gg); gs = wave_sum(gs); gy = wave_sum(gy); sy = wave_sum(sy); yy = wave_sum(yy);
   if (lane == 0) {
@@ -577,13 +587,19 @@ extern "C" size_t stv_lbfgsc_workspace_bytes(size_t n, int history) {
 }
 
 namespace {
-struct StepGeom { size_t nn; int tile, ntiles, nparts; CWs w; };
+struct StepGeom { size_t nn; int tile, ntiles, nparts, pgroups; CWs w; };
 inline StepGeom step_geom(void* workspace, size_t n, int history) {
   StepGeom g;
   g.nn = align_up(n, 4096);
   g.tile = tile_floats(n);
   g.ntiles = (int)(g.nn / g.tile);
   g.nparts = g.ntiles * 4;
+  // sweep A: enough workgroups to cover the HBM latency (>= ~768 where the tile count alone does not give them)
+  static const int forced_pg = getenv("STV_LBFGS_PGROUPS") ? atoi(getenv("STV_LBFGS_PGROUPS")) : 0;   // tuning aid
+  // (measured: 256^2, 192 tiles -> 4 groups: step 0.549 -> 0.515 ms; 512^2, 384 tiles: 2 groups change nothing)
+  g.pgroups = forced_pg > 0 ? forced_pg : (g.ntiles >= 256 ? 1 : (768 + g.ntiles - 1) / g.ntiles);
+  if (g.pgroups > 4) g.pgroups = 4;
+  if (g.pgroups < 1) g.pgroups = 1;
   g.w = carve(workspace, n, history, g.nparts);
   return g;
 }
@@ -601,11 +617,11 @@ extern "C" int stv_lbfgsc_dots(const float* grad, void* state, void* workspace, 
   CState* s = static_cast<CState*>(state);
   const StepGeom g = step_geom(workspace, n, history);
   if (g.tile == 4096)
-    hipLaunchKernelGGL(pass_a_kernel<4>, dim3(g.ntiles), dim3(256), 0, st, grad, s, g.w, n, g.nn, history, g.nparts);
+    hipLaunchKernelGGL(pass_a_kernel<4>, dim3(g.ntiles * g.pgroups), dim3(256), 0, st, grad, s, g.w, n, g.nn, history, g.nparts, g.ntiles, g.pgroups);
   else if (g.tile == 2048)
-    hipLaunchKernelGGL(pass_a_kernel<2>, dim3(g.ntiles), dim3(256), 0, st, grad, s, g.w, n, g.nn, history, g.nparts);
+    hipLaunchKernelGGL(pass_a_kernel<2>, dim3(g.ntiles * g.pgroups), dim3(256), 0, st, grad, s, g.w, n, g.nn, history, g.nparts, g.ntiles, g.pgroups);
   else
-    hipLaunchKernelGGL(pass_a_kernel<1>, dim3(g.ntiles), dim3(256), 0, st, grad, s, g.w, n, g.nn, history, g.nparts);
+    hipLaunchKernelGGL(pass_a_kernel<1>, dim3(g.ntiles * g.pgroups), dim3(256), 0, st, grad, s, g.w, n, g.nn, history, g.nparts, g.ntiles, g.pgroups);
   hipLaunchKernelGGL(reduce_kernel, dim3(5 * m_max + NSCAL), dim3(256), 0, st, s, g.w, history, g.nparts);
   STV_CHECK_LAUNCH();
   return STV_OK;
