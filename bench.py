@@ -190,7 +190,7 @@ def run_gpu(args, rank: int, world: int, device: torch.device, size: int, steps:
     st = opt.device_state() if hasattr(opt, "device_state") else {}
     info["lbfgs"] = {k: st.get(k) for k in ("n_iter", "hist_len", "skip", "no_update")}
     if rank == 0 and profile:
-        # per-op device time of the fused step (HIP events on the launch stream), 3 passes
+        # per-op device time of the fused step (HIP events on the launch stream), median of 5 passes
         eng = next(iter(model._engines.values()))
         prog = next(p for k, p in eng._programs.items() if k[0] == "fused")
         OP = {n[3:]: getattr(_lib, n) for n in dir(_lib) if n.startswith("OP_")}
@@ -213,8 +213,9 @@ def run_gpu(args, rank: int, world: int, device: torch.device, size: int, steps:
             fwd_gram_ctx_ms = replay_ms(lambda: eng.forward_losses(xin))
             prog.profile()
             # every op 8x inside its event pair: an event pair costs as much as a short kernel
-            passes = [prog.profile(reps=8) for _ in range(3)]
-        ms = [sum(p[i] for p in passes) / len(passes) for i in range(prog.n_ops)]
+            passes = [prog.profile(reps=8) for _ in range(5)]
+        # per op the MEDIAN of the passes: one disturbed pass (a clock dip, a neighbour's tail) must not rate a kernel
+        ms = [sorted(p[i] for p in passes)[len(passes) // 2] for i in range(prog.n_ops)]
         groups: dict = {}
         for meta, fl, t in zip(prog.op_meta, prog.op_flags, ms, strict=True):
             g = kernel_group(meta, OP, 1 if precision == "bf16" else 0, fl)
