@@ -58,6 +58,9 @@ __device__ unsigned long long g_stv_stamps[8 * 16384];
 #define STV_DIAG 0
 #endif
 
+#ifndef STV_HOLD_LAST
+#define STV_HOLD_LAST 1
+#endif
 #ifndef STV_STORE_AUX
 #define STV_STORE_AUX 0      // cache-policy bits of the output stores (diagnostic builds: 2 = nt, 16 = sc1)
 #endif
@@ -250,6 +253,28 @@ __device__ __forceinline__ void conv_mainloop(const Phase<typename C::Elem>& ph,
   // by column (dx outer, dy inner): the MT+2 halo-tile rows a wave needs for one dx serve all
   // three dy, so a stage reads 3*(MT+2) A fragments instead of 9*MT.  Fragments are fetched ahead
   // of the MFMAs that use them.
+  // The MFMAs of a stage's LAST tap step(s) are held back across the barrier (-DSTV_HOLD_LAST=n steps, 0 = off):
+  // their operands sit in registers, so they can be issued behind the next stage's first LDS reads and cover
+  // that round trip - right after a barrier both waves of a SIMD would otherwise wait for it with the matrix
+  // pipe idle.  Same products in the same order on the same accumulators: results unchanged bit for bit.
+  // (Before the first stage the held operands are zero: four MFMAs that add nothing.)
+  constexpr int NHOLD = (STV_HOLD_LAST < NSTEP) ? STV_HOLD_LAST : NSTEP;      // steps held back (0: none)
+  FragT hold_a[NHOLD > 0 ? NHOLD : 1][C::MT], hold_b[NHOLD > 0 ? NHOLD : 1][C::NT];
+#pragma unroll
+  for (int q = 0; q < NHOLD; ++q) {
+#pragma unroll
+    for (int mt = 0; mt < C::MT; ++mt) hold_a[q][mt] = FragT{};
+#pragma unroll
+    for (int nt = 0; nt < C::NT; ++nt) hold_b[q][nt] = FragT{};
+  }
+  auto flush_held = [&]() {
+#pragma unroll
+    for (int q = 0; q < NHOLD; ++q)
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < C::NT; ++nt) mma<T>(hold_b[q][nt], hold_a[q][mt], acc[mt][nt]);
+  };
   auto run_stage = [&](const char* cur, char* fill, int l) {
     FragT af[2][C::AROWS];
     FragT bf[PFB + 1][C::NT];
@@ -269,6 +294,11 @@ __device__ __forceinline__ void conv_mainloop(const Phase<typename C::Elem>& ph,
 #pragma unroll
     for (int q = 1; q < PFB; ++q)
       if (q < NSTEP) load_b(q);
+    if (NHOLD > 0) {
+      __builtin_amdgcn_sched_barrier(0);
+      flush_held();                              // the previous stage's last step, in the shadow of the reads above
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int step = 0; step < NSTEP; ++step) {
       const int dx = step / C::ND, dy = step % C::ND;
@@ -283,10 +313,19 @@ __device__ __forceinline__ void conv_mainloop(const Phase<typename C::Elem>& ph,
       for (int k = step * PER; k < (step + 1) * PER; ++k)
         if (k < C::PPW) dma(k, l + C::NBUF - 1, fill);
       __builtin_amdgcn_sched_barrier(0);
+      if (step >= NSTEP - NHOLD) {
+        constexpr int dummy = 0; (void)dummy;
+        const int q = step - (NSTEP - NHOLD);
 #pragma unroll
-      for (int mt = 0; mt < C::MT; ++mt)
+        for (int mt = 0; mt < C::MT; ++mt) hold_a[q][mt] = af[dx & 1][mt + dy];
 #pragma unroll
-        for (int nt = 0; nt < C::NT; ++nt) mma<T>(bf[step % (PFB + 1)][nt], af[dx & 1][mt + dy], acc[mt][nt]);   // D[cout][pixel]
+        for (int nt = 0; nt < C::NT; ++nt) hold_b[q][nt] = bf[step % (PFB + 1)][nt];
+      } else {
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < C::NT; ++nt) mma<T>(bf[step % (PFB + 1)][nt], af[dx & 1][mt + dy], acc[mt][nt]);   // D[cout][pixel]
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     // round l + 1 has landed once at most the pieces of the rounds after it are still in flight;
@@ -314,6 +353,7 @@ __device__ __forceinline__ void conv_mainloop(const Phase<typename C::Elem>& ph,
 #pragma unroll
   for (int k = 0; k + 1 < C::NBUF; ++k)
     if (c + k < nrounds) run_stage(ring + k * C::STAGE_BYTES, ring + ((k + C::NBUF - 1) % C::NBUF) * C::STAGE_BYTES, c + k);
+  if (NHOLD > 0) flush_held();                   // the last stage's held steps
   // the zero-fill DMAs of the rounds past the end still target the ring: drain them before the
   // C tile takes over the same LDS
   wait_vmcnt<0>();
