@@ -134,7 +134,9 @@ def _halo_worker(rank: int, world: int, port: int, q) -> None:
     dist.destroy_process_group()
 
 
-def test_halo_exchange_strips_equal_the_unsharded_result_adam_and_lbfgs():
+@pytest.mark.parametrize("world", [2, 4])
+def test_halo_exchange_strips_equal_the_unsharded_result_adam_and_lbfgs(world):
+    """world = 4: the two middle ranks exchange halo rows with BOTH neighbours (the configs[4] layout)."""
     import numpy as np
 
     from style_transfer_visualizer_amd import optimizers
@@ -157,18 +159,19 @@ def test_halo_exchange_strips_equal_the_unsharded_result_adam_and_lbfgs():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_halo_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_halo_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = dict(q.get(timeout=600) for _ in range(2))
+    got = dict(q.get(timeout=600) for _ in range(world))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    assert got[0]["rows"] == (0, 256) and got[1]["rows"] == (256, 512)
+    rows = 512 // world
+    assert [got[r]["rows"] for r in range(world)] == [(r * rows, (r + 1) * rows) for r in range(world)]
     # 13 convs forward + 13 backward: one exchange each (26 per closure)
     assert got[0]["exchanges"] == 26
     gscale = float(g_ref.abs().max())
-    for r in (0, 1):
+    for r in range(world):
         c0, c1 = got[r]["rows"]
         for name in ("adam", "lbfgs"):
             scores = torch.from_numpy(got[r][f"{name}_scores"])
@@ -190,8 +193,9 @@ def test_halo_exchange_strips_equal_the_unsharded_result_adam_and_lbfgs():
             assert dev_img < bound, f"rank {r} {name}: image after 3 steps differs by {dev_img:.2e} of its range"
     # both ranks hold the same gathered image, and ran the SAME scalar recursion: after the all-reduce
     # the inner products are bit-identical on every rank, so the optimizer state must be too
-    assert np.array_equal(got[0]["lbfgs_image"], got[1]["lbfgs_image"])
-    assert got[0]["lbfgs_state"] == got[1]["lbfgs_state"]
+    for r in range(1, world):
+        assert np.array_equal(got[0]["lbfgs_image"], got[r]["lbfgs_image"])
+        assert got[0]["lbfgs_state"] == got[r]["lbfgs_state"]
     st = got[0]["lbfgs_state"]
     assert (st["n_iter"], st["hist_len"], st["skip"]) == (ref_state["n_iter"], ref_state["hist_len"], ref_state["skip"]) == (3, 2, 0)
     assert st["H_diag"] == pytest.approx(ref_state["H_diag"], rel=1e-3)
