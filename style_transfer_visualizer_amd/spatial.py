@@ -383,8 +383,6 @@ class HaloShard:
         up, down = self.rank - 1, self.rank + 1
         if self.world == 1:
             return
-        def as_bytes(t):
-            return t.view(torch.uint8) if t.is_contiguous() else t
         if self._host_p2p:
             # gloo (rehearsal on one GPU): no GPU point-to-point -> through host memory
             reqs, back = [], []
@@ -401,13 +399,20 @@ class HaloShard:
             for dst, h in back:
                 dst.copy_(h.view(dst.dtype).reshape(dst.shape))
             return
-        p2p = []
+        # RCCL send/recv wants contiguous tensors: a row of an NHWC activation is, a row of the NCHW image
+        # ([1, 3, W] out of [1, 3, H, W]) is not - those go through a small contiguous staging row
+        p2p, back = [], []
         for peer, src, dst in ((up, send_top, recv_top), (down, send_bot, recv_bot)):
             if 0 <= peer < self.world:
-                p2p.append(dist.P2POp(dist.irecv, as_bytes(dst), peer, self.group))
-                p2p.append(dist.P2POp(dist.isend, as_bytes(src), peer, self.group))
+                rbuf = dst if dst.is_contiguous() else torch.empty(dst.shape, dtype=dst.dtype, device=dst.device)
+                if rbuf is not dst:
+                    back.append((dst, rbuf))
+                p2p.append(dist.P2POp(dist.irecv, rbuf.view(torch.uint8), peer, self.group))
+                p2p.append(dist.P2POp(dist.isend, src.detach().contiguous().view(torch.uint8), peer, self.group))
         for r in dist.batch_isend_irecv(p2p):
             r.wait()
+        for dst, rbuf in back:
+            dst.copy_(rbuf)
 
     # -- one evaluation -------------------------------------------------------------------------------
     def loss_and_grad(self) -> torch.Tensor:
