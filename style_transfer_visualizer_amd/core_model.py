@@ -280,17 +280,23 @@ class _Engine:
         deferred = [tap for tap in s.style_taps if mode == "1" or (mode == "auto" and small(tap))]
         if len(deferred) < 2 or len(deferred) > 8 or not x.is_cuda:
             deferred = []
-        tail = []
-        if deferred:
+        held = {id(tap) for tap in deferred}
+
+        def batched_tail() -> list:
+            # built AFTER the forward ops: whether the first layer leaves its own Gram slabs
+            # (tap.partials_fused) is decided while those are emitted
+            if not deferred:
+                return []
             specs = [dict(tap=tap, target=tap.target, loss_part=self.parts[tap.parts_off:],
                           sgrad=tap.sgrad if with_seed else None, coef=style_coef) for tap in deferred]
-            tail.append(s.gram_multi_op(specs))
+            return [s.gram_multi_op(specs)]
         if deferred and len(deferred) == len(s.style_taps):
+            fwd = s.forward_ops(x)
+            tail = batched_tail()
             for tap in s.content_taps:
                 tail += self._tap_loss_ops(tap, style_coef=style_coef, coef_dev=None, with_seed=with_seed,
                                            content_coef=content_coef)
-            return s.forward_ops(x) + tail
-        held = {id(tap) for tap in deferred}
+            return fwd + tail
 
         def after(node):
             out = []
@@ -300,11 +306,13 @@ class _Engine:
                                               content_coef=content_coef)
             return out
         if os.environ.get("STV_LOSS_INTERLEAVE", "1") == "1":
-            return self.sched.forward_ops(x, after_node=after) + tail
+            fwd = self.sched.forward_ops(x, after_node=after)
+            return fwd + batched_tail()
+        fwd = self.sched.forward_ops(x)
         inline = []
         for node in self.sched.nodes:
             inline += after(node)
-        return self.sched.forward_ops(x) + inline + tail
+        return fwd + inline + batched_tail()
 
     def _combine_op(self, style_w: float, content_w: float, score_log: tuple | None = None):
         """``score_log`` = (ring fp32 [3, capacity], device counter int32 [1]): the combine kernel also appends
@@ -409,15 +417,18 @@ class _Engine:
         v = t[0].permute(1, 2, 0)
         if v.is_contiguous() and v.dtype == self.dtype and v.device == self.device:
             return v
+        # The entry keeps the source tensor alive and is only reused for that very tensor object: a key of
+        # (address, version) alone can be recycled by the caching allocator for a NEW target tensor once the
+        # old one is freed, and the stale converted copy would be returned.
         cache = self.__dict__.setdefault("_target_cache", {})
         key = (t.data_ptr(), t._version, tuple(t.shape), t.dtype)
         hit = cache.get(key)
-        if hit is None:
+        if hit is None or hit[0] is not t:
             if len(cache) > 8:
                 cache.clear()
-            hit = v.to(self.device, self.dtype).contiguous()
+            hit = (t, v.to(self.device, self.dtype).contiguous())
             cache[key] = hit
-        return hit
+        return hit[1]
 
     def _as_target(self, t: torch.Tensor, shape: tuple, dtype: torch.dtype) -> torch.Tensor:
         if tuple(t.shape) != shape:

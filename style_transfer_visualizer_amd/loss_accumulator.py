@@ -31,7 +31,11 @@ class LossAccumulator:
     """Ring-buffered loss history on the device, floats on demand."""
 
     def __init__(self, *, log_every: int, history_capacity: int | None, track_history: bool,
-                 device: torch.device, dtype: torch.dtype) -> None:
+                 device: torch.device, dtype: torch.dtype, audit_ring: bool = False) -> None:
+        """``audit_ring`` (extension): keep the device ring even when ``track_history`` is off (CSV mode), so
+        that every step's scores can still be inspected at the next flush (:meth:`drain_unchecked`) - the
+        reference checks each step's losses for non-finite values as it goes (optimization.py:375-391);
+        ``export_history`` stays empty."""
         self._log_every = max(1, log_every)
         self._capacity = max(1, history_capacity or DEFAULT_HISTORY_CAPACITY)
         self._track = track_history
@@ -39,8 +43,10 @@ class LossAccumulator:
         # fp16 images keep fp16 buffers; everything else (incl. bf16) logs in fp32
         self._buffer_dtype = torch.float16 if dtype == torch.float16 else torch.float32
         self._ring: torch.Tensor | None = None
-        if track_history:
+        self._ringed = track_history or audit_ring
+        if self._ringed:
             self._ring = torch.empty(3, self._capacity, dtype=self._buffer_dtype, device=device)
+        self._unchecked: list[int] = []   # step ids recorded since the last drain_unchecked()
         self._next = 0            # slot the next record goes to
         self._count = 0           # valid records in the ring
         self._records = 0         # records ever written
@@ -53,7 +59,7 @@ class LossAccumulator:
         history itself (``stv_loss_combine_log``: slot = counter % capacity, counter += 1) - the per-step copy
         kernel then disappears from the step.  None when there is no fp32 device ring to share.  Records that
         still arrive through :meth:`accumulate` without ``logged_by_producer`` keep the counter in step."""
-        if not self._track or self._ring is None or self._ring.dtype != torch.float32 or not self._ring.is_cuda:
+        if not self._ringed or self._ring is None or self._ring.dtype != torch.float32 or not self._ring.is_cuda:
             return None
         if self._counter is None:
             self._counter = torch.full((1,), self._records, dtype=torch.int32, device=self._ring.device)
@@ -72,7 +78,7 @@ class LossAccumulator:
     @property
     def history_truncated(self) -> bool:
         """True once the ring has overwritten its oldest entries."""
-        return self._records > self._capacity
+        return self._track and self._records > self._capacity
 
     def accumulate(self, step_idx: int, style_loss: torch.Tensor, content_loss: torch.Tensor,
                    total_loss: torch.Tensor, *, force: bool = False, logged_by_producer: bool = False,
@@ -84,10 +90,13 @@ class LossAccumulator:
             triple = torch.stack((style_loss.detach().reshape(()), content_loss.detach().reshape(()),
                                   total_loss.detach().reshape(())))
         self._pending = (step_idx, triple)
-        if self._track:
+        if self._ringed:
             if self._ring is None:
                 msg = "History buffers are uninitialized."
                 raise RuntimeError(msg)
+            self._unchecked.append(step_idx)
+            if len(self._unchecked) > 2 * self._capacity:       # nobody drains (autograd path): stay bounded
+                del self._unchecked[:-self._capacity]
             if not (logged_by_producer and self._counter is not None):
                 self._ring[:, self._next] = triple.to(dtype=self._buffer_dtype, device=self._device)
                 if self._counter is not None:
@@ -132,6 +141,23 @@ class LossAccumulator:
             window = torch.cat((self._ring[:, start:], self._ring[:, :self._count - (self._capacity - start)]), dim=1)
         rows = window.cpu().tolist()
         return dict(zip(_KEYS, rows, strict=True))
+
+    def drain_unchecked(self) -> list[tuple[int, float, float, float]]:
+        """(step, style, content, total) of every step recorded since the previous call, oldest first (at most
+        ``capacity`` of them) - one device-to-host copy.  Lets the caller examine EVERY step's scores at the
+        logging cadence without a host synchronisation per step."""
+        steps, self._unchecked = self._unchecked, []
+        if not steps or self._ring is None:
+            return []
+        steps = steps[-min(self._count, self._capacity):]
+        k = len(steps)
+        start = (self._next - k) % self._capacity
+        if start + k <= self._capacity:
+            window = self._ring[:, start:start + k]
+        else:
+            window = torch.cat((self._ring[:, start:], self._ring[:, :k - (self._capacity - start)]), dim=1)
+        s, c, t = window.cpu().tolist()
+        return [(step, float(a), float(b), float(d)) for step, a, b, d in zip(steps, s, c, t, strict=True)]
 
     def _sync_pending(self) -> LoggedLoss | None:
         if self._pending is None:

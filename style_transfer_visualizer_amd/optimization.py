@@ -9,10 +9,12 @@ error texts).  Differences, all on the device side:
   step is one fused command-buffer launch that leaves ``input_img.grad``
   populated - no autograd graph, no tiny reduction kernels;
 * the default optimizer for a GPU image is the device-resident ``HipLBFGS``;
-* finite-ness of the losses is checked from the values that are copied to the
-  host anyway at the ``log_every`` cadence, instead of three blocking
-  ``if not torch.isfinite(t)`` reads per step (reference optimization.py:383-391);
-  the warning texts are the same.
+* finite-ness of the losses is checked for EVERY step, like the reference does
+  (optimization.py:375-391), but at the ``log_every`` cadence: each flush copies the
+  scores of all steps since the previous flush out of the device ring in one
+  transfer (``LossAccumulator.drain_unchecked``) instead of three blocking
+  ``if not torch.isfinite(t)`` reads per step; same warning texts and step ids, also
+  in CSV mode (where the ring is kept for this purpose only).
 """
 from __future__ import annotations
 
@@ -196,9 +198,8 @@ class OptimizationRunner:
         elapsed = time.time() - started
         self._log_optimization_summary()
         acc = self._loss_accumulator
+        self._audit_unchecked_steps()            # steps after the last logging point
         history: LossHistory = acc.export_history() if (acc is not None and acc.tracks_history) else {}
-        if history:
-            self._warn_nonfinite_history(history)
         return self.input_img, history, elapsed
 
     # ------------------------------------------------------------------- set-up
@@ -244,7 +245,8 @@ class OptimizationRunner:
         capacity = min(steps, DEFAULT_HISTORY_CAPACITY)
         self._loss_accumulator = LossAccumulator(
             log_every=log_every, history_capacity=capacity, track_history=track_history,
-            device=self.input_img.device, dtype=self.input_img.dtype)
+            device=self.input_img.device, dtype=self.input_img.dtype,
+            audit_ring=True)      # CSV mode: the ring is still kept, for the per-step finite checks at the flush
         if track_history and steps > capacity:
             logger.warning(
                 "Long run detected (%d steps). In-memory loss history is "
@@ -314,8 +316,7 @@ class OptimizationRunner:
         logged = self._record_losses(tensors)
         if logged is not None:
             self._latest_logged = logged
-            if self._fused:
-                self._warn_nonfinite(logged.style_loss, logged.content_loss, logged.total_loss, logged.step)
+            self._audit_unchecked_steps()
             metrics = StepMetrics(logged.step, logged.style_loss, logged.content_loss, logged.total_loss)
         else:
             metrics = StepMetrics(step=tensors.step)
@@ -350,17 +351,15 @@ class OptimizationRunner:
         if logger.isEnabledFor(logging.DEBUG):
             logger.debug("Step %d: Style %.4e, Content %.4e, Total %.4e", step_idx, style, content, total)
 
-    def _warn_nonfinite_history(self, history: LossHistory) -> None:
-        """Fused path: steps between logging points are checked from the exported history."""
-        if not self._fused:
+    def _audit_unchecked_steps(self) -> None:
+        """Fused path: the reference's per-step finite checks (optimization.py:375-391), run for every step
+        since the previous logging point from one copy of the device ring.  The autograd path has checked
+        each step as it went (`_check_finite`)."""
+        acc = self._loss_accumulator
+        if not self._fused or acc is None:
             return
-        totals = history.get("total_loss", [])
-        first = self._step_index - len(totals) + 1
-        every = max(1, self.config.output.log_every)
-        for off, value in enumerate(totals):
-            step = first + off
-            if step % every and not math.isfinite(value):
-                logger.warning("Non-finite total loss at step %d, using previous loss", step)
+        for step, style, content, total in acc.drain_unchecked():
+            self._warn_nonfinite(style, content, total, step)
 
     def _maybe_write_video_frame(self, metrics: StepMetrics) -> None:
         """Every ``save_every`` accepted steps, hand a uint8 HWC frame to the sinks."""

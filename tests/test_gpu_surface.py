@@ -307,3 +307,34 @@ def test_style_transfer_batch_runs_independent_pairs(tmp_path, monkeypatch):
     assert all(float(t.min()) >= 0.0 and float(t.max()) <= 1.0 for t in out)
     assert not torch.equal(out[0], out[1])
     assert (tmp_path / "out" / "stylized_c0_x_s.png").is_file() and (tmp_path / "out" / "stylized_c1_x_s.png").is_file()
+
+
+# ------------------------------------------------------------------- a2/a5 replaced content targets
+def test_fresh_content_targets_are_never_served_from_a_stale_cache(monkeypatch):
+    """The reference reads ``model.content_targets`` at every forward (core_model.py:266-295), so a user may
+    assign new [1,C,H,W] tensors at any time.  The engine caches their NHWC conversion; the caching allocator
+    hands a freed target's address (and version 0) to the next fresh tensor, so the cache must recognise the
+    tensor object, not its address: three fresh NCHW-contiguous targets in a row, loss checked each time."""
+    cfg = (8, 8, "M", 16, 16)
+    weights = synthetic.synthetic_conv_weights(3, cfg)
+    monkeypatch.setattr(core_model, "initialize_vgg", lambda: core_model.build_vgg_features(weights, cfg).eval())
+    model = core_model.StyleContentModel([0], [5]).to(DEV)
+    content, style, x0 = (synthetic.synthetic_image(s, 32, 32) for s in (0, 1, 2))
+    model.set_targets(style.to(DEV), content.to(DEV))
+    oracle = ocm.OracleModel(ocm.vgg_program(weights, cfg), [0], [5])
+    oracle.set_targets(style, content)
+    x = x0.to(DEV).requires_grad_(True)
+    shape = tuple(model.content_targets[0].shape)
+    seen = set()
+    for k in range(4):
+        tgt = torch.randn(shape, generator=torch.Generator().manual_seed(100 + k)) * (k + 1)
+        fresh = tgt.to(DEV)                                   # NCHW-contiguous: goes through the conversion cache
+        seen.add(fresh.data_ptr())
+        model.content_targets = [fresh]
+        oracle.content_targets = [tgt]
+        _, c, _ = model.loss_and_grad(x, 1e5, 1.0)
+        _, c_ref, _, _ = ocm.loss_and_grad(oracle, x0, 1e5, 1.0)
+        assert float(c) == pytest.approx(float(c_ref), rel=1e-5), f"assignment {k}: content loss is that of another target"
+        del fresh
+    # (on the caching allocator the later targets reuse the first one's address: the case the cache key alone missed)
+    print(f"distinct target addresses over 4 assignments: {len(seen)}")

@@ -77,3 +77,19 @@ def test_defaults_and_edge_values():
     half = LossAccumulator(log_every=1, history_capacity=2, track_history=True, device=CPU, dtype=torch.float16)
     assert half._ring.dtype == torch.float16  # fp16 images keep fp16 buffers, everything else fp32
     assert acc._ring.dtype == torch.float32
+
+
+def test_audit_ring_keeps_scores_without_tracking_history():
+    """audit_ring: per-step scores stay inspectable at the flush although the history itself is off (CSV mode);
+    the reference-visible surface (tracks_history, export_history, history_truncated) is unchanged."""
+    acc = LossAccumulator(log_every=3, history_capacity=4, track_history=False, device=torch.device("cpu"),
+                          dtype=torch.float32, audit_ring=True)
+    for step in range(1, 8):
+        acc.accumulate(step, torch.tensor(float(step)), torch.tensor(0.5), torch.tensor(2.0 * step))
+        if step == 3:
+            assert acc.drain_unchecked() == [(1, 1.0, 0.5, 2.0), (2, 2.0, 0.5, 4.0), (3, 3.0, 0.5, 6.0)]
+    # four more records since the drain: the ring (capacity 4) wrapped, all four are still there
+    assert acc.drain_unchecked() == [(4, 4.0, 0.5, 8.0), (5, 5.0, 0.5, 10.0), (6, 6.0, 0.5, 12.0), (7, 7.0, 0.5, 14.0)]
+    assert acc.drain_unchecked() == []
+    assert not acc.tracks_history and not acc.history_truncated
+    assert acc.export_history() == {"style_loss": [], "content_loss": [], "total_loss": []}

@@ -232,3 +232,34 @@ def test_fused_model_path_is_used_when_offered():
     assert Fused.calls == 3 and len(history["total_loss"]) == 3
     assert torch.allclose(x.detach(), torch.full_like(x, 0.25 - 0.3))
     assert opt_mod.append_crossfade is not None
+
+
+@pytest.mark.parametrize("csv_mode", [False, True])
+def test_fused_path_warns_for_nonfinite_steps_between_logging_points(caplog, tmp_path, csv_mode):
+    """Reference optimization.py:375-391 checks every step's three scores.  The fused path checks them at the
+    flush from the device ring - every step since the last flush, with its own step id, also in CSV mode
+    (where the history itself is off) and for steps after the last logging point."""
+    class Fused(nn.Module):
+        calls = 0
+
+        def loss_and_grad(self, x, style_w, content_w):
+            Fused.calls += 1
+            x.grad = torch.zeros_like(x)
+            bad = {3: (float("inf"), 0.0), 5: (1.0, float("nan")), 7: (float("nan"), 1.0)}.get(Fused.calls, (1.0, 2.0))
+            s, c = torch.tensor(bad[0]), torch.tensor(bad[1])
+            return s, c, style_w * s + content_w * c
+    x = _img()
+    cfg = _cfg(steps=7, log_every=4, log_loss=str(tmp_path / "loss.csv") if csv_mode else None)
+    logger = logging.getLogger("style_transfer")
+    logger.propagate = True
+    try:
+        with caplog.at_level(logging.WARNING, logger="style_transfer"):
+            runner = OptimizationRunner(Fused(), x, cfg, optimizer=torch.optim.SGD([x], lr=0.0), progress_bar=Bar())
+            _, history, _ = runner.run()
+    finally:
+        logger.propagate = False
+    assert (history == {}) if csv_mode else (len(history["total_loss"]) == 7)
+    msgs = [r.getMessage() for r in caplog.records if "Non-finite" in r.getMessage()]
+    assert msgs == ["Non-finite style score at step 3", "Non-finite total loss at step 3, using previous loss",
+                    "Non-finite content score at step 5", "Non-finite total loss at step 5, using previous loss",
+                    "Non-finite style score at step 7", "Non-finite total loss at step 7, using previous loss"]
