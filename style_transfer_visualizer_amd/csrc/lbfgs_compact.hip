@@ -18,6 +18,7 @@
 //   pass B : second sweep forms d, applies x += t*d and prev_g = g.
 // HBM traffic per step: (4m + 8) vectors instead of ~(8m) with 2m+4 launches.
 #include <stdlib.h>
+#include <string.h>
 
 #include <type_traits>
 
@@ -522,7 +523,14 @@ __global__ __launch_bounds__(256) void solve_kernel(CState* st, CWs w, int hist,
 }
 
 // ---- pass B: form the direction, move x, remember g ------------------------------------------------
-template <int U>
+// d = cg g + sum_j cy_j y_j + cs_j s_j is a sum of 2m + 1 terms that cancel to a result far smaller than its
+// largest partial sums (the two-loop recursion deflates q step by step; here the terms arrive in whatever order
+// the history is walked).  Accumulated in fp32 the direction was 7-10x further from the float64 update than
+// torch's fp32 vector recursion once m > 60 (tests/test_gpu_lbfgs_long.py; CPU emulation of this algorithm:
+// fp64 inner products change nothing, fp64 accumulation HERE brings it to the reference's own level), so the
+// accumulators are double (ACC64): every product of two floats is exact in double, the sum is rounded to
+// fp32 once.  The sweep stays bandwidth-bound: 2 conversions + 2 DP FMAs per element and pair beside 8 bytes.
+template <int U, bool ACC64>
 __global__ __launch_bounds__(256) void pass_b_kernel(float* __restrict__ x, const float* __restrict__ g,
                                                      const CState* st, CWs w, size_t n, size_t nn, int hist) {
   if (st->skip) return;
@@ -532,19 +540,21 @@ __global__ __launch_bounds__(256) void pass_b_kernel(float* __restrict__ x, cons
   const int m = st->hist_len, head = st->head;
   const float cg = st->cg, t = st->t;
   const bool move = st->no_update == 0;
-  f32x4 acc[U], gv[U];
+  using acc_t = typename std::conditional<ACC64, double, float>::type;
+  acc_t acc[U][4];
+  f32x4 gv[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const size_t idx = base + (size_t)(u * 256 + tid) * 4;
     gv[u] = ld4_guard(g, idx, n);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc[u][e] = cg * gv[u][e];
+    for (int e = 0; e < 4; ++e) acc[u][e] = (acc_t)cg * (acc_t)gv[u][e];
   }
   // newest pair first: pass A walked the history oldest-to-newest just before, so its tail is what
   // the Infinity Cache still holds
   for (int jj = m - 1; jj >= 0; --jj) {
     const int slot = (head + jj) % S;
-    const float cs = st->cs[slot], cy = st->cy[slot];
+    const acc_t cs = (acc_t)st->cs[slot], cy = (acc_t)st->cy[slot];
     const float* __restrict__ sj = w.S + (size_t)slot * nn;
     const float* __restrict__ yj = w.Y + (size_t)slot * nn;
 #pragma unroll
@@ -553,18 +563,24 @@ __global__ __launch_bounds__(256) void pass_b_kernel(float* __restrict__ x, cons
       const f32x4 s4 = *reinterpret_cast<const f32x4*>(sj + idx);
       const f32x4 y4 = *reinterpret_cast<const f32x4*>(yj + idx);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[u][e] = fmaf(cs, s4[e], fmaf(cy, y4[e], acc[u][e]));
+      for (int e = 0; e < 4; ++e) {
+        if constexpr (ACC64) acc[u][e] = fma(cs, (double)s4[e], fma(cy, (double)y4[e], acc[u][e]));
+        else acc[u][e] = fmaf(cs, s4[e], fmaf(cy, y4[e], acc[u][e]));
+      }
     }
   }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const size_t idx = base + (size_t)(u * 256 + tid) * 4;
-    *reinterpret_cast<f32x4*>(w.d + idx) = acc[u];
+    f32x4 dv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dv[e] = (float)acc[u][e];
+    *reinterpret_cast<f32x4*>(w.d + idx) = dv;
     *reinterpret_cast<f32x4*>(w.prev_g + idx) = gv[u];
     if (move) {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        if (idx + e < n) x[idx + e] = fmaf(t, acc[u][e], x[idx + e]);
+        if (idx + e < n) x[idx + e] = fmaf(t, dv[e], x[idx + e]);
     }
   }
 }
@@ -640,12 +656,17 @@ extern "C" int stv_lbfgsc_apply(float* x, const float* grad, void* state, void* 
   if (stv_set_max_lds(reinterpret_cast<const void*>(&solve_kernel), 2 * MAX_HIST * (MAX_HIST | 1) * (int)sizeof(float)) != STV_OK)
     return STV_ERR_LAUNCH;
   hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(256), lds, st, s, g.w, history, lr, tol_grad, tol_change);
-  if (g.tile == 4096)
-    hipLaunchKernelGGL(pass_b_kernel<4>, dim3(g.ntiles), dim3(256), 0, st, x, grad, s, g.w, n, g.nn, history);
-  else if (g.tile == 2048)
-    hipLaunchKernelGGL(pass_b_kernel<2>, dim3(g.ntiles), dim3(256), 0, st, x, grad, s, g.w, n, g.nn, history);
-  else
-    hipLaunchKernelGGL(pass_b_kernel<1>, dim3(g.ntiles), dim3(256), 0, st, x, grad, s, g.w, n, g.nn, history);
+  // A/B aid: STV_LBFGS_ACC=f32 restores the fp32 accumulation of the direction (less accurate, see pass_b_kernel)
+  static const bool acc64 = !(getenv("STV_LBFGS_ACC") && strcmp(getenv("STV_LBFGS_ACC"), "f32") == 0);
+#define STV_LAUNCH_PASS_B(U_)                                                                                              \
+  do {                                                                                                                     \
+    if (acc64) hipLaunchKernelGGL((pass_b_kernel<U_, true>), dim3(g.ntiles), dim3(256), 0, st, x, grad, s, g.w, n, g.nn, history); \
+    else hipLaunchKernelGGL((pass_b_kernel<U_, false>), dim3(g.ntiles), dim3(256), 0, st, x, grad, s, g.w, n, g.nn, history);      \
+  } while (0)
+  if (g.tile == 4096) STV_LAUNCH_PASS_B(4);
+  else if (g.tile == 2048) STV_LAUNCH_PASS_B(2);
+  else STV_LAUNCH_PASS_B(1);
+#undef STV_LAUNCH_PASS_B
   STV_CHECK_LAUNCH();
   return STV_OK;
 }
