@@ -89,10 +89,40 @@ def trajectory_sensitivity(weights, cfg, content, style, x0, *, style_layers, co
     return max(float((run(s, ew) - base).abs().max()) / scale for s in (1, 2, 3) for ew in (False, True))
 
 
+def per_step_sensitivity(weights, cfg, content, style, x0, *, style_layers, content_layers, style_w,
+                         content_w, steps, optimizer, adam_lr, eps=3e-7):
+    """``trajectory_sensitivity`` for the image after EVERY step (fixtures that store ``x_steps``): array
+    [steps] of max |x_k - x_k_unperturbed| / max|x_k| over the same six perturbed runs."""
+    model = ocm.OracleModel(ocm.vgg_program(weights, cfg), style_layers, content_layers)
+    model.set_targets(style, content)
+
+    def run(seed, elementwise=False):
+        gen = torch.Generator().manual_seed(seed)
+
+        def lg(x):
+            s, c, t, g = ocm.loss_and_grad(model, x, style_w, content_w)
+            if seed and elementwise:
+                g = g * (1 + eps * torch.randn(g.shape, generator=gen))
+            elif seed:
+                g = g * (1 + eps * float(torch.randn((), generator=gen)))
+            return s, c, t, g
+        return optim_ref.run_loop(lg, x0, steps, optimizer=optimizer, lr=adam_lr if optimizer == "adam" else None,
+                                  keep_steps=True)["x_steps"]
+    base = run(0)
+    out = np.zeros(steps)
+    for s in (1, 2, 3):
+        for ew in (False, True):
+            for k, (a, b) in enumerate(zip(run(s, ew), base, strict=True)):
+                scale = float(b.abs().max())
+                dev = float((a - b).abs().max()) / scale if np.isfinite(scale) and scale > 0 else float("nan")
+                out[k] = max(out[k], dev) if np.isfinite(dev) else float("nan")
+    return out
+
+
 def run_case(ref, name, *, cfg, cfg_name, wseed, hw_content, hw_style, style_layers,
              content_layers, init_method, steps, optimizer, style_w=1e5, content_w=1.0,
              gain_first=1.0, bias_scale=0.0, normalize=True, adam_lr=1e-3,
-             subsample_targets=False):
+             subsample_targets=False, store_steps=False):
     ref_core, ref_opt, ref_config, _ = ref
     weights = _weights(cfg, wseed, gain_first, bias_scale)
     ref_core.initialize_vgg = lambda: ref_harness.build_sequential(weights, cfg)
@@ -125,11 +155,14 @@ def run_case(ref, name, *, cfg, cfg_name, wseed, hw_content, hw_style, style_lay
 
     grads = {}
     logged = []
+    x_steps = []
 
     def on_end(metrics):
         if metrics.step == 1:
             grads["g1"] = input_img.grad.detach().clone()
         logged.append((metrics.step, metrics.has_values))
+        if store_steps:
+            x_steps.append(input_img.detach().clone().numpy())
 
     runner = ref_opt.OptimizationRunner(
         model, input_img, config, optimizer=opt, progress_bar=_Bar(),
@@ -162,6 +195,13 @@ def run_case(ref, name, *, cfg, cfg_name, wseed, hw_content, hw_style, style_lay
         "closure_calls": np.asarray(runner._closure_calls, dtype=np.int64),
         "logged_steps": np.asarray([s for s, has in logged if has], dtype=np.int64),
     }
+    if store_steps:
+        # the image after every step: a trajectory that overshoots (L-BFGS without line search can) is
+        # compared at the last step whose loss is still comparable, not only at the end
+        arrays["x_steps"] = np.stack(x_steps)
+        arrays["x_steps_sensitivity"] = per_step_sensitivity(
+            weights, cfg, content, style, x0, style_layers=style_layers, content_layers=content_layers,
+            style_w=style_w, content_w=content_w, steps=steps, optimizer=optimizer, adam_lr=adam_lr)
     for i, t in enumerate(model.style_targets):
         a = t.numpy()
         if subsample_targets and a.shape[0] > 128:
@@ -238,13 +278,22 @@ def main():
              normalize=False, bias_scale=0.05, **common)
     run_case(ref, "mini_white_adam", init_method="white", steps=5, optimizer="adam", adam_lr=1e-2, **common)
     run_case(ref, "mini_clamp_lbfgs", init_method="white", steps=4, optimizer="lbfgs",
+             gain_first=12.0, store_steps=True, **common)
+    run_case(ref, "mini_clamp_adam", init_method="white", steps=5, optimizer="adam", adam_lr=1e-2,
              gain_first=12.0, **common)
     run_case(ref, "tiny_taps_lbfgs", cfg=TINY_CFG, cfg_name="tiny", wseed=5, hw_content=(16, 16),
              hw_style=(16, 24), style_layers=(0, 2, 4), content_layers=(1, 3),
-             init_method="white", steps=4, optimizer="lbfgs", bias_scale=0.1)
+             init_method="white", steps=4, optimizer="lbfgs", bias_scale=0.1, store_steps=True)
     run_case(ref, "vgg19_white_lbfgs", cfg=synthetic.VGG19_CFG, cfg_name="vgg19", wseed=0,
              hw_content=(64, 64), hw_style=(64, 96), style_layers=S, content_layers=C,
-             init_method="white", steps=3, optimizer="lbfgs", subsample_targets=True)
+             init_method="white", steps=3, optimizer="lbfgs", subsample_targets=True, store_steps=True)
+    # full width, NOT chaotic (measured sensitivity 2e-7): the fixture that must meet north_star's 1e-4 per
+    # pixel outright.  (Adam from the white image is not such a case - sensitivity 3e-3: Adam moves a pixel
+    # by ~lr whatever the size of its gradient, and the white image has many near-zero gradient entries whose
+    # sign is rounding noise; from the random start image - the reference's default init - every entry is large.)
+    run_case(ref, "vgg19_random_adam", cfg=synthetic.VGG19_CFG, cfg_name="vgg19", wseed=0,
+             hw_content=(64, 64), hw_style=(64, 96), style_layers=S, content_layers=C,
+             init_method="random", steps=4, optimizer="adam", adam_lr=1e-2, subsample_targets=True)
     run_case(ref, "vgg19_content_lbfgs", cfg=synthetic.VGG19_CFG, cfg_name="vgg19", wseed=0,
              hw_content=(64, 64), hw_style=(64, 96), style_layers=S, content_layers=C,
              init_method="content", steps=4, optimizer="lbfgs", style_w=1e8, subsample_targets=True)

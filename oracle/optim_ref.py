@@ -161,6 +161,7 @@ def run_loop(
     *,
     optimizer: str = "lbfgs",
     lr: float | None = None,
+    keep_steps: bool = False,
 ) -> dict:
     """Step loop with the reference's accounting (optimization.py:162-202).
 
@@ -176,6 +177,7 @@ def run_loop(
         raise ValueError(optimizer)
     hist = {"style": [], "content": [], "total": []}
     first_grad = None
+    x_steps: list[torch.Tensor] = []          # image after each step (keep_steps)
 
     for _ in range(steps):
         rec = {}
@@ -192,4 +194,6 @@ def run_loop(
         hist["style"].append(rec["s"])
         hist["content"].append(rec["c"])
         hist["total"].append(rec["t"])
-    return {"x": x, "history": hist, "first_grad": first_grad, "optimizer": opt}
+        if keep_steps:
+            x_steps.append(x.detach().clone())
+    return {"x": x, "history": hist, "first_grad": first_grad, "optimizer": opt, "x_steps": x_steps}

@@ -98,7 +98,13 @@ def initialize_input(content_img: torch.Tensor, method: str) -> torch.Tensor:
     if method == "content":
         start = content_img.clone()
     elif method == "random":
-        start = torch.randn_like(content_img)
+        if content_img.is_cuda:
+            # The reference's --device cpu path (the one north_star compares with) draws randn_like on the
+            # CPU generator; a draw on the GPU generator could never match it on the same --seed.  Same
+            # generator, same shape/dtype -> the same values, then one copy to the device.
+            start = torch.randn(content_img.shape, dtype=content_img.dtype).to(content_img.device)
+        else:
+            start = torch.randn_like(content_img)
     elif method == "white":
         start = torch.ones_like(content_img)
     else:
@@ -128,6 +134,22 @@ def build_vgg_features(weights: list[tuple[torch.Tensor, torch.Tensor]] | None =
     return nn.Sequential(*layers)
 
 
+def consume_classifier_init() -> None:
+    """Advance the CPU generator as constructing the rest of torchvision's VGG19 would.
+
+    The reference builds ``vgg19(weights=IMAGENET1K_V1)`` (core_model.py:114) AFTER seeding
+    (main.py:36) and BEFORE drawing the ``random`` start image (core_model.py:92): torchvision's
+    ``_vgg`` runs ``VGG(make_layers(cfg), init_weights=False)``, i.e. the default ``reset_parameters`` of
+    16 ``Conv2d`` (kaiming_uniform_ weight + uniform_ bias each, in layer order) and then of the classifier's
+    ``Linear(25088, 4096)``, ``Linear(4096, 4096)``, ``Linear(4096, 1000)``; the checkpoint is loaded over them.
+    ``build_vgg_features`` constructs the same 16 ``Conv2d`` in the same order; this function does the three
+    ``Linear`` (by constructing and dropping them: identical consumption by construction, ~0.5 GB / 1 s once
+    per run), so that ``randn`` afterwards continues where the reference's would.
+    """
+    for fan_in, fan_out in ((512 * 7 * 7, 4096), (4096, 4096), (4096, 1000)):
+        nn.Linear(fan_in, fan_out)
+
+
 def initialize_vgg() -> nn.Module:
     """Frozen VGG19 feature stack (reference core_model.py:103-117).
 
@@ -142,6 +164,7 @@ def initialize_vgg() -> nn.Module:
     if synth is not None:
         logger.info("Using synthetic VGG19 weights (seed %s)", synth)
         vgg = build_vgg_features(synthetic.synthetic_conv_weights(int(synth)))
+        consume_classifier_init()
     else:
         if cache_path.exists():
             logger.info("Using cached VGG19 weights at %s", cache_path)
@@ -156,6 +179,7 @@ def initialize_vgg() -> nn.Module:
                        "checkpoint there, or set STV_SYNTHETIC_WEIGHTS=<seed> for synthetic weights.")
                 raise RuntimeError(msg) from None
             vgg = build_vgg_features()
+            consume_classifier_init()
             state = torch.load(cache_path, map_location="cpu", weights_only=True)
             feats = {k[len("features."):]: v for k, v in state.items() if k.startswith("features.")}
             vgg.load_state_dict(feats)

@@ -202,6 +202,9 @@ __global__ __launch_bounds__(256) void conv_first_dgrad_c64(const T* __restrict_
   for (int tap = 0; tap < 9; ++tap) {
     const char* src = smem + ((py + tap / 3) * FH + (px + tap % 3)) * PITCH;
     const float* __restrict__ wp = wd + tap * 3 * CO;          // wave-uniform -> scalar loads
+    // blocked summation (this is the parity mode's kernel): one tap's 64 products per fresh accumulator,
+    // added to the running sum - chains of 32 + 9 instead of 288 sequential additions per lane half
+    f32x2 q0 = {0.0f, 0.0f}, q1 = {0.0f, 0.0f}, q2 = {0.0f, 0.0f};
 #pragma unroll 2
     for (int v = 0; v < VPP; ++v) {
       float g[kVec];
@@ -209,11 +212,12 @@ __global__ __launch_bounds__(256) void conv_first_dgrad_c64(const T* __restrict_
 #pragma unroll
       for (int e = 0; e < kVec; e += 2) {      // v_pk_fma_f32: two channels per instruction
         const f32x2 g2 = {g[e], g[e + 1]};
-        p0 = __builtin_elementwise_fma(g2, *reinterpret_cast<const f32x2*>(wp + 0 * CO + v * kVec + e), p0);
-        p1 = __builtin_elementwise_fma(g2, *reinterpret_cast<const f32x2*>(wp + 1 * CO + v * kVec + e), p1);
-        p2 = __builtin_elementwise_fma(g2, *reinterpret_cast<const f32x2*>(wp + 2 * CO + v * kVec + e), p2);
+        q0 = __builtin_elementwise_fma(g2, *reinterpret_cast<const f32x2*>(wp + 0 * CO + v * kVec + e), q0);
+        q1 = __builtin_elementwise_fma(g2, *reinterpret_cast<const f32x2*>(wp + 1 * CO + v * kVec + e), q1);
+        q2 = __builtin_elementwise_fma(g2, *reinterpret_cast<const f32x2*>(wp + 2 * CO + v * kVec + e), q2);
       }
     }
+    p0 += q0; p1 += q1; p2 += q2;
   }
   const float a0 = p0[0] + p0[1], a1 = p1[0] + p1[1], a2 = p2[0] + p2[1];
   const int gy = y0 + py, gx = x0 + px;

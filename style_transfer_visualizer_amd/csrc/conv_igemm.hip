@@ -258,7 +258,13 @@ __device__ __forceinline__ void conv_mainloop(const Phase<typename C::Elem>& ph,
   // that round trip - right after a barrier both waves of a SIMD would otherwise wait for it with the matrix
   // pipe idle.  Same products in the same order on the same accumulators: results unchanged bit for bit.
   // (Before the first stage the held operands are zero: four MFMAs that add nothing.)
-  constexpr int NHOLD = (STV_HOLD_LAST < NSTEP) ? STV_HOLD_LAST : NSTEP;      // steps held back (0: none)
+  // fp32 = the parity mode: BLOCKED summation.  One accumulator chain over all 9 Cin products of an output
+  // (up to 4,608 sequential fp32 additions) left the fp32 gradient 2.6-6.6x further from its float64 value than
+  // the reference's CPU path at 512^2 / 1024^2; here every K-stage (8 channels x 9 taps = 72 products) is summed
+  // in a fresh accumulator that is then added to the running sum - chains of 72 and Cin/8 instead of 9 Cin.
+  // Speed is not the point of this mode (no held-back step either: it would straddle two stage sums).
+  constexpr bool BLOCKED = sizeof(T) == 4;
+  constexpr int NHOLD = BLOCKED ? 0 : ((STV_HOLD_LAST < NSTEP) ? STV_HOLD_LAST : NSTEP);      // steps held back (0: none)
   FragT hold_a[NHOLD > 0 ? NHOLD : 1][C::MT], hold_b[NHOLD > 0 ? NHOLD : 1][C::NT];
 #pragma unroll
   for (int q = 0; q < NHOLD; ++q) {
@@ -278,6 +284,15 @@ __device__ __forceinline__ void conv_mainloop(const Phase<typename C::Elem>& ph,
   auto run_stage = [&](const char* cur, char* fill, int l) {
     FragT af[2][C::AROWS];
     FragT bf[PFB + 1][C::NT];
+    f32x16 sacc[BLOCKED ? C::MT : 1][BLOCKED ? C::NT : 1];      // this stage's own sum (fp32 mode)
+    if constexpr (BLOCKED) {
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) sacc[mt][nt][i] = 0.0f;
+    }
     auto load_a = [&](int dx, int j, int set) {
       const FragT v = *reinterpret_cast<const FragT*>(cur + a_addr[dx][j]);
       af[set][j] = RELU ? relu_frag(v, 0u) : v;
@@ -324,9 +339,20 @@ __device__ __forceinline__ void conv_mainloop(const Phase<typename C::Elem>& ph,
 #pragma unroll
         for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < C::NT; ++nt) mma<T>(bf[step % (PFB + 1)][nt], af[dx & 1][mt + dy], acc[mt][nt]);   // D[cout][pixel]
+          for (int nt = 0; nt < C::NT; ++nt) {
+            if constexpr (BLOCKED) mma<T>(bf[step % (PFB + 1)][nt], af[dx & 1][mt + dy], sacc[mt][nt]);
+            else mma<T>(bf[step % (PFB + 1)][nt], af[dx & 1][mt + dy], acc[mt][nt]);   // D[cout][pixel]
+          }
       }
       __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (BLOCKED) {
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[mt][nt][i] += sacc[mt][nt][i];
     }
     // round l + 1 has landed once at most the pieces of the rounds after it are still in flight;
     // the barrier then also says every wave is done reading `cur`, which the next fill overwrites
@@ -768,6 +794,10 @@ constexpr int kNumCfg = 11;     // 9 / 10 = 16x64 (four row blocks per wave: hal
 const int kCfgTH[kNumCfg] = {8, 8, 4, 4, 4, 8, 4, 2, 1, 16, 16}, kCfgBN[kNumCfg] = {128, 64, 128, 64, 64, 64, 64, 64, 64, 64, 64};
 
 bool cfg_valid(int cfg, int cout) { return cfg >= 0 && cfg < kNumCfg && !(cout <= 64 && kCfgBN[cfg] == 128); }
+// fp32 (parity mode) keeps a second accumulator set per K-stage (blocked summation): the eight-wave tiles with 64+
+// accumulator registers per lane (8x128, 16x64) would spill at their 256-register budget, so they are served by
+// the four-wave 4x128 tile (512 registers per wave) and the 8x64 tiles instead.
+int fp32_cfg(int cfg) { return cfg == 0 ? 2 : (cfg == 9 ? 1 : (cfg == 10 ? 5 : cfg)); }
 
 // Measured choices (stv_conv_tune), keyed by shape.
 struct TuneEntry { int H, W, cin, cout, taps, esize, cfg; };
@@ -809,17 +839,18 @@ constexpr int kRouteTaps = STV_TUNE_ROUTE;
 int choose_cfg(int H, int W, int cin, int cout, int elem_bytes, int taps = 9) {
   const int kVec = 16 / elem_bytes, CK = 32 / elem_bytes;
   if ((cin % CK) || (cout % kVec)) return -1;
+  auto served = [&](int cfg) { return elem_bytes == 4 ? fp32_cfg(cfg) : cfg; };
   if (const char* force = getenv("STV_CONV_CFG")) {   // tuning aid (tools/conv_sweep.py)
     const int f = atoi(force);
-    if (cfg_valid(f, cout)) return f;
+    if (cfg_valid(f, cout)) return served(f);
   }
   // STV_CONV_TUNE=0 pins the analytic choice even when another caller in this process has
   // measured the shape already (tests that assert near fp32 rounding want one summation order)
   const char* tune = getenv("STV_CONV_TUNE");
   const int t = (tune && atoi(tune) == 0) ? -1 : tuned_cfg(H, W, cin, cout, taps, elem_bytes);
-  if (t >= 0) return t;
+  if (t >= 0) return served(t);
   const int m = model_cfg(H, W, cin, cout);
-  return (taps == kRouteTaps && (m == 0 || m == 2)) ? 3 : m;       // untuned routed dgrad: 4x64 where the model says 128-wide
+  return served((taps == kRouteTaps && (m == 0 || m == 2)) ? 3 : m);       // untuned routed dgrad: 4x64 where the model says 128-wide
 }
 
 template <typename T, int TAPS>
@@ -922,8 +953,9 @@ int tune_typed(int H, int W, int cin, int cout, int key_taps, hipStream_t st) {
     (void)hipEventSynchronize(e1);
     (void)hipEventElapsedTime(&t_flush, e0, e1);
   }
-  const int base = route ? ((model_cfg(H, W, cin, cout) == 0 || model_cfg(H, W, cin, cout) == 2) ? 3 : model_cfg(H, W, cin, cout))
-                         : model_cfg(H, W, cin, cout);
+  int base = route ? ((model_cfg(H, W, cin, cout) == 0 || model_cfg(H, W, cin, cout) == 2) ? 3 : model_cfg(H, W, cin, cout))
+                   : model_cfg(H, W, cin, cout);
+  if (sizeof(T) == 4) base = fp32_cfg(base);
   int best = base;
   float t_best = 3.4e38f, t_base = 3.4e38f;
   int rc = STV_OK;
@@ -935,7 +967,7 @@ int tune_typed(int H, int W, int cin, int cout, int key_taps, hipStream_t st) {
   for (int cfg = 0; cfg < kNumCfg; ++cfg) t_cfg[cfg] = 3.4e38f;
   for (int round = 0; round < 2 && rc == STV_OK; ++round)
     for (int cfg = 0; cfg < ncfg && rc == STV_OK; ++cfg) {
-      if (!cfg_valid(cfg, cout)) continue;
+      if (!cfg_valid(cfg, cout) || (sizeof(T) == 4 && fp32_cfg(cfg) != cfg)) continue;
       const int kWarm = 2, kReps = flushbuf ? 6 : 10;
       for (int i = 0; i < kWarm && rc == STV_OK; ++i)
         rc = taps == 9 ? launch_mfma<T, 9>(a, cfg, st) : launch_mfma<T, 1>(a, cfg, st);

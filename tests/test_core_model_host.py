@@ -194,3 +194,42 @@ def test_initialize_vgg_loads_cached_checkpoint(tmp_path, monkeypatch, caplog):
     model = core_model.StyleContentModel([0, 5, 10, 19, 28], [21])
     assert len(model.vgg_blocks) == 6 and model.style_ids == [0, 1, 2, 3, 5] and model.content_ids == [4]
     assert torch.equal(model.vgg_blocks[1][4].weight, state["features.5.weight"])
+
+
+# ------------------------------------------------------------------ a6: same-seed `random` start image
+def test_random_init_is_the_reference_draw_for_the_same_seed():
+    """tests/golden/mini_random_lbfgs_nonorm.npz["x0"] is the start image the UNMODIFIED reference drew
+    (core_model.py:66-100, ``randn_like`` on the CPU generator) after ``torch.manual_seed(0)`` and after its
+    ``initialize_vgg`` seam had constructed the network (oracle/make_golden.py).  Seeding, constructing the same
+    network through OUR builder and calling ``initialize_input`` must reproduce it bit for bit - nothing is copied in."""
+    from tests.conftest import GoldenCase
+    case = GoldenCase("mini_random_lbfgs_nonorm")
+    assert case.meta["init_method"] == "random"
+    content, _ = case.images()
+    torch.manual_seed(0)
+    core_model.build_vgg_features(case.weights(), case.cfg)          # the module constructions consume the generator
+    x0 = core_model.initialize_input(content, "random")
+    assert x0.requires_grad and torch.equal(x0.detach(), case.tensor("x0"))
+
+
+def test_initialize_vgg_consumes_the_generator_like_torchvision_vgg19(monkeypatch):
+    """What ``torchvision.models.vgg19(weights=...)`` constructs before the checkpoint is loaded over it
+    (torchvision 0.24 models/vgg.py: ``VGG(make_layers(cfgs["E"]), init_weights=False)``): 16 Conv2d(k=3, pad=1)
+    in layer order, then Linear(25088, 4096), Linear(4096, 4096), Linear(4096, 1000) - each with torch's default
+    ``reset_parameters``.  The torchvision-free branches of ``initialize_vgg`` must leave the CPU generator in the
+    same state, so that the ``random`` start image drawn afterwards is the one the reference's CPU path draws."""
+    def torchvision_like_construction() -> None:
+        cin = 3
+        for v in synthetic.VGG19_CFG:
+            if v != "M":
+                nn.Conv2d(cin, int(v), kernel_size=3, padding=1)
+                cin = int(v)
+        nn.Linear(512 * 7 * 7, 4096), nn.Linear(4096, 4096), nn.Linear(4096, 1000)
+    torch.manual_seed(1234)
+    torchvision_like_construction()
+    want = torch.randn(1, 3, 5, 7)
+    monkeypatch.setenv("STV_SYNTHETIC_WEIGHTS", "0")
+    torch.manual_seed(1234)
+    core_model.initialize_vgg()
+    got = core_model.initialize_input(torch.zeros(1, 3, 5, 7), "random")
+    assert torch.equal(got.detach(), want)

@@ -20,10 +20,17 @@ Tolerances (measured values are printed in the parity table at the end of the ru
   to it as the reference's fp32 CPU path is (x3, floor 2e-5), the criterion
   tests/test_gpu_model.py::test_every_step_matches_oracle_at_same_image applies at fixture sizes.
   MFMA K-loops add the 9*Cin products of an output one after the other, oneDNN's kernels in 16
-  SIMD lanes: rounding error of a sequential sum of n terms grows like sqrt(n), of a 16-way
-  blocked one like sqrt(n/16), so a factor up to 4 between the two paths' errors is arithmetic,
-  not a defect; the bound is 8x the CPU path's own error (measured ratios: 1.4 .. 7.3), with a floor of
-  4e-3 because that CPU error itself swings by 10x between images.
+  SIMD lanes.  Round 3: the fp32 kernels sum every K-stage in a fresh accumulator (blocked summation,
+  csrc/conv_igemm.hip) and every stored activation / gradient of the HIP path is now CLOSER to float64
+  than the CPU path's (tests/diag/diag_three_way.py: e.g. 4.2e-7 vs 5.1e-7 at conv5_1).  What is left in
+  the plain "vs fp64" rows (1e-3 for BOTH paths) is not rounding: with 3e7 activations per evaluation a
+  few ReLU / max-pool decisions are float64 near-ties that any fp32 evaluation may take either way, and
+  each moves the gradient by O(1e-2) of scale inside that unit's receptive field (tests/parity_util.py).
+  So the criterion has two parts: (a) on the SAME branch - float64 oracle with the path's own decisions
+  imposed - the HIP gradient must be at least as close to float64 as the CPU path's is on ITS branch
+  (x2, floor 1e-6), and given the HIP decisions the fp32 CPU oracle must agree with the HIP gradient per
+  pixel to 1e-3 of scale (measured ~1e-5); (b) the plain rows stay as a sanity bound: 4x the CPU path's
+  own, floor 2.5e-3.
 * bf16: losses 2e-3 relative (measured ~1e-4).  The gradient is compared with the oracle that
   rounds to bf16 at the same points, but only as a sanity bound (rms 0.25 of its rms; measured
   0.11-0.13): bf16 storage makes the network chaotic under rounding - see
@@ -42,6 +49,7 @@ import torch
 from oracle import core_model_ref as ocm
 from oracle import optim_ref
 from style_transfer_visualizer_amd import _lib, core_model, ops, synthetic
+from tests import parity_util as pu
 from tests.conftest import record_parity
 
 pytestmark = pytest.mark.gpu
@@ -52,7 +60,7 @@ STYLE_W, CONTENT_W = 1e5, 1.0
 # error swings by 10x from one image to the next (1.5e-4 .. 1.4e-3 at 512^2 within one run): a pure ratio
 # bound would hinge on the luckiest CPU sample.  Anything a wrong tile edge, tap or mask would cause is
 # far above this floor; rounding-level effects are below it.
-GRAD_FLOOR = 4e-3
+GRAD_FLOOR = 2.5e-3
 
 
 def _fused_style_taps(model) -> list[int]:
@@ -89,6 +97,7 @@ def test_fullsize_closure_and_lbfgs_steps_match_oracle(size, precision, monkeypa
         s, c, t = model.loss_and_grad(x, STYLE_W, CONTENT_W)
         return model, x, (float(s), float(c), float(t)), x.grad.detach().cpu().clone()
     model, x, l_pin, g_pin = hip_model("0")
+    dec0 = pu.hip_decisions(model) if precision == "fp32" else None
     fused = _fused_style_taps(model)
     model_t, x_t, l_tun, g_tun = hip_model("1")
     tiles = {"pinned": [], "tuned": []}
@@ -126,6 +135,25 @@ def test_fullsize_closure_and_lbfgs_steps_match_oracle(size, precision, monkeypa
     record_parity(case, "content target (of max)", dev, 2e-5 if not bf16 else 8e-3)
     assert dev <= (2e-5 if not bf16 else 8e-3)
 
+    nl = pu.n_program_layers(S_LAYERS, C_LAYERS)
+
+    def check_same_branch(tag: str, g, g_cpu, xc, dec_hip) -> None:
+        """(a) of the module docstring: accuracy with the discrete decisions held fixed."""
+        dec_cpu = pu.oracle_decisions(oracle.program, xc, nl)
+        flips = pu.count_flips(dec_hip, dec_cpu)
+        x64 = xc.double()
+        g64_h = ocm.loss_and_grad(pu.lock(oracle64, dec_hip), x64, STYLE_W, CONTENT_W)[3]
+        g64_c = ocm.loss_and_grad(pu.lock(oracle64, dec_cpu), x64, STYLE_W, CONTENT_W)[3]
+        err_hip = float((g.double() - g64_h).norm() / g64_h.norm())
+        err_cpu = float((g_cpu.double() - g64_c).norm() / g64_c.norm())
+        record_parity(case, f"{tag} grad vs fp64 on the same branch (rel rms)", err_hip, max(2 * err_cpu, 1e-6),
+                      f"reference's CPU-fp32 path on its own branch: {err_cpu:.2e}; {flips} ReLU/pool decisions differ between the two fp32 paths")
+        assert err_hip <= max(2 * err_cpu, 1e-6), f"{case} {tag}: HIP {err_hip:.2e} vs CPU-fp32 {err_cpu:.2e} (same-branch float64)"
+        g32_h = ocm.loss_and_grad(pu.lock(oracle, dec_hip), xc, STYLE_W, CONTENT_W)[3]
+        mx = float((g - g32_h).abs().max() / g32_h.abs().max())
+        record_parity(case, f"{tag} grad HIP vs CPU-fp32 given the HIP decisions, per pixel max (of scale)", mx, 1e-3)
+        assert mx <= 1e-3
+
     def check(tag: str, losses, g, ref, g64=None) -> None:
         s_ref, c_ref, t_ref, g_ref = ref
         for nm, got, want in (("style", losses[0], float(s_ref)), ("content", losses[1], float(c_ref)),
@@ -137,9 +165,9 @@ def test_fullsize_closure_and_lbfgs_steps_match_oracle(size, precision, monkeypa
             err_hip = float((g.double() - g64).norm() / g64.norm())
             err_cpu = float((g_ref.double() - g64).norm() / g64.norm())
             mx, rms, _ = _grad_stats(g, g_ref, 2e-4)
-            record_parity(case, f"{tag} grad vs fp64 (rel rms)", err_hip, max(8 * err_cpu, GRAD_FLOOR),
-                          f"reference's CPU-fp32 path vs fp64: {err_cpu:.2e}; HIP vs CPU-fp32 directly: rms {rms:.1e} max {mx:.1e} of scale")
-            assert err_hip <= max(8 * err_cpu, GRAD_FLOOR), f"{case} {tag}: HIP {err_hip:.2e} vs fp64, CPU-fp32 {err_cpu:.2e}"
+            record_parity(case, f"{tag} grad vs fp64 (rel rms)", err_hip, max(4 * err_cpu, GRAD_FLOOR),
+                          f"decision near-ties included; reference's CPU-fp32 path vs fp64: {err_cpu:.2e}; HIP vs CPU-fp32 directly: rms {rms:.1e} max {mx:.1e} of scale")
+            assert err_hip <= max(4 * err_cpu, GRAD_FLOOR), f"{case} {tag}: HIP {err_hip:.2e} vs fp64, CPU-fp32 {err_cpu:.2e}"
         else:
             rel = float((g - g_ref).norm() / g_ref.norm())
             record_parity(case, f"{tag} grad rms (of rms)", rel, grms_tol, "sanity bound only: rounding chaos, see test_gpu_bf16_layerwise.py")
@@ -151,6 +179,8 @@ def test_fullsize_closure_and_lbfgs_steps_match_oracle(size, precision, monkeypa
     check("step1 pinned-tiles", l_pin, g_pin, ref0, g64_0)
     check("step1 tuned-tiles", l_tun, g_tun, ref0, g64_0)
     del model_t, x_t
+    if not bf16:      # `model` was evaluated at x0 before the tuned twin was built: its activations are still those
+        check_same_branch("step1", g_pin, ref0[3], x0, dec0)
 
     # ---- three L-BFGS steps: oracle at the same image, oracle optimizer fed the HIP gradients --------
     # The update is built from fp32 dot products over 0.8M / 3.1M elements, and from the second pair on
@@ -181,7 +211,10 @@ def test_fullsize_closure_and_lbfgs_steps_match_oracle(size, precision, monkeypa
         # step at 512^2 and at the LAST step at 1024^2; the L-BFGS update is checked at every step either way
         if size <= 512 or step == 3:
             xc = x.detach().cpu()
-            check(f"step{step + 1}", losses, g, ocm.loss_and_grad(oracle, xc, STYLE_W, CONTENT_W), g64_at(xc))
+            ref_k = ocm.loss_and_grad(oracle, xc, STYLE_W, CONTENT_W)
+            check(f"step{step + 1}", losses, g, ref_k, g64_at(xc))
+            if not bf16 and step == 3:
+                check_same_branch(f"step{step + 1}", g, ref_k[3], xc, pu.hip_decisions(model))
     print(f"{case}: oracle time {time.time() - t0:.0f} s")
     del model, x
     torch.cuda.empty_cache()

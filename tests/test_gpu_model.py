@@ -14,6 +14,7 @@ import torch
 from oracle import core_model_ref as ocm
 from style_transfer_visualizer_amd import config as stv_config
 from style_transfer_visualizer_amd import core_model, optimization, optimizers, synthetic
+from tests import parity_util as pu
 from tests.conftest import GoldenCase, record_parity
 
 pytestmark = pytest.mark.gpu
@@ -46,10 +47,13 @@ def _build(case: GoldenCase, monkeypatch, precision="fp32"):
     cfg.output.log_every = 2
     cfg.video.create_video = False
     content, style = case.images()
+    torch.manual_seed(0)        # as oracle/make_golden.py seeded the reference (runtime/device.py:31-42 does it for the CLI)
     model, input_img, opt = core_model.prepare_model_and_input(content.to(DEV), style.to(DEV), DEV, oc,
                                                                precision=precision)
-    with torch.no_grad():
-        input_img.copy_(case.tensor("x0").to(DEV))     # identical start (covers init_method=random)
+    # Nothing is copied in: the start image must BE the reference's, bit for bit - also for init_method=random,
+    # whose draw comes from the CPU generator after the network's module constructions consumed it
+    # (reference core_model.py:66-100 on its --device cpu path).
+    assert torch.equal(input_img.detach().cpu(), case.tensor("x0")), f"{m['init_method']} start image differs from the reference's"
     return cfg, model, input_img, opt
 
 
@@ -72,13 +76,36 @@ def test_targets_and_first_step_match_reference(golden_case: GoldenCase, monkeyp
 
     g_ref = case.arrays["grad_step1"]
     gscale = np.abs(g_ref).max()
+    name = m.get("name", "fixture")
     # fused path
     s, c, tot = model.loss_and_grad(x, m["style_w"], m["content_w"])
     assert float(s) == pytest.approx(case.arrays["style_loss"][0], rel=2e-4)
     assert float(c) == pytest.approx(case.arrays["content_loss"][0], rel=2e-4)
     assert float(tot) == pytest.approx(case.arrays["total_loss"][0], rel=2e-4)
-    np.testing.assert_allclose(x.grad.cpu().numpy(), g_ref, rtol=0, atol=2e-4 * gscale)
     fused_grad = x.grad.clone()
+    dev = float(np.abs(fused_grad.cpu().numpy() - g_ref).max() / gscale)
+    if dev <= 2e-4:
+        record_parity(name, "step-1 gradient vs reference (of scale)", dev, 2e-4)
+    else:
+        # Not rounding: the two fp32 evaluations sit on different sides of a ReLU / max-pool near-tie
+        # (tests/parity_util.py).  That claim is checked, not assumed: the differing decisions must be few and
+        # genuine float64 near-ties, and on the branch the HIP path took the oracle must reproduce its gradient.
+        nl = pu.n_program_layers(m["style_layers"], m["content_layers"])
+        content, style = case.images()
+        oracle = ocm.OracleModel(ocm.vgg_program(case.weights(), case.cfg), m["style_layers"], m["content_layers"])
+        oracle.set_targets(style, content)
+        x0 = case.tensor("x0")
+        d_hip, d_cpu = pu.hip_decisions(model), pu.oracle_decisions(oracle.program, x0, nl)
+        flips = pu.count_flips(d_hip, d_cpu)
+        prog64 = ocm.vgg_program([(w.double(), b.double()) for w, b in case.weights()], case.cfg)
+        gap = pu.flip_gaps(d_hip, d_cpu, prog64, x0.double(), nl)
+        _, _, _, g_locked = ocm.loss_and_grad(pu.lock(oracle, d_hip), x0, m["style_w"], m["content_w"])
+        dev_locked = float((fused_grad.cpu() - g_locked).abs().max() / gscale)
+        record_parity(name, "step-1 gradient vs reference on the HIP path's branch (of scale)", dev_locked, 2e-4,
+                      f"plain comparison {dev:.1e}: {flips} ReLU/pool decision(s) differ, float64 gap <= {gap:.1e} of the layer rms")
+        assert 0 < flips <= 16 and gap < 1e-5, f"{name}: {flips} decisions differ, largest float64 gap {gap:.2e}"
+        assert dev_locked <= 2e-4, f"{name}: gradient differs by {dev_locked:.2e} of scale on the same branch"
+        g_ref = g_locked.numpy()
     # autograd path: model(x) -> lists of 0-d tensors -> loss.backward()
     x.grad = None
     s_losses, c_losses = model(x)
@@ -97,10 +124,15 @@ def test_trajectory_matches_reference(golden_case: GoldenCase, monkeypatch):
     cfg, model, x, opt = _build(case, monkeypatch)
     if m["optimizer"] == "adam":
         opt = optimizers.HipAdam([x], lr=m["adam_lr"])
-    seen = []
+    seen, snaps, decisions = [], [], []
+
+    def on_end(mt):
+        seen.append((mt.step, mt.has_values))
+        snaps.append(x.detach().cpu().clone())
+        decisions.append(pu.hip_decisions(model))         # of the evaluation this step's update was built from
     runner = optimization.OptimizationRunner(
         model, x, cfg, optimizer=opt, progress_bar=_Bar(),
-        callbacks=optimization.OptimizationCallbacks(on_step_end=lambda mt: seen.append((mt.step, mt.has_values))))
+        callbacks=optimization.OptimizationCallbacks(on_step_end=on_end))
     out, history, _ = runner.run()
     steps = m["steps"]
     # integer bookkeeping: bit-exact
@@ -108,69 +140,114 @@ def test_trajectory_matches_reference(golden_case: GoldenCase, monkeypatch):
     assert [s for s, has in seen if has] == case.arrays["logged_steps"].tolist()
     assert runner._closure_calls == int(case.arrays["closure_calls"])
     assert len(history["total_loss"]) == steps
-    # losses per step and final image.  Tolerance: north_star's 1e-4 per pixel, widened only for
-    # fixtures whose reference trajectory itself amplifies 2-ulp gradient noise beyond that
-    # (GoldenCase.pixel_tolerance / oracle.make_golden.trajectory_sensitivity).
-    ptol = case.pixel_tolerance()
-    # A reference step that overshoots by many orders of magnitude (L-BFGS without line search
-    # can: e.g. 5.6e8 -> 8.3e29 in mini_clamp_lbfgs) leaves nothing numerically meaningful to
-    # compare afterwards; values are compared up to and including the first such step.
-    ref_total = case.arrays["total_loss"]
-    blown = np.nonzero(ref_total > 1e6 * ref_total[0])[0]
-    upto = int(blown[0]) + 1 if len(blown) else steps
-    xf = case.arrays["x_final"]
-    dev = float(np.abs(out.detach().cpu().numpy() - xf).max() / np.abs(xf).max())
     name = case.meta.get("name", request_name(case))
-    base_tol = ptol
-    probed = False
-    if not len(blown) and dev > ptol:
-        # The fixture's sensitivity was probed with 3e-7 gradient noise; two correct fp32
-        # evaluations differ by more than that (summation order: ~1e-6).  Before calling the
-        # deviation an error, measure what THIS path does to itself under a last-bit change of the
-        # start image: a trajectory that amplifies one ulp to `self_dev` cannot be pinned tighter
-        # than a small multiple of it.  A systematic error does not shrink under this probe.
-        # The widened window is CAPPED (1e-2 of the image range) and its use is recorded in the
-        # parity table; such a fixture must additionally match the reference on its first steps -
-        # before the amplification - at the plain 1e-4 (below).
-        probed = True
-        _, model2, x2, opt2 = _build(case, monkeypatch)
-        with torch.no_grad():
-            g = torch.Generator().manual_seed(7)
-            x2.mul_(1.0 + 1.2e-7 * (2.0 * torch.rand(x2.shape, generator=g) - 1.0).to(x2.device))
-        if m["optimizer"] == "adam":
-            opt2 = optimizers.HipAdam([x2], lr=m["adam_lr"])
-        out2, _, _ = optimization.OptimizationRunner(model2, x2, cfg, optimizer=opt2, progress_bar=_Bar()).run()
-        self_dev = float((out2 - out).abs().max() / out.abs().max())
-        ptol = min(max(ptol, 10.0 * self_dev), PROBE_TOL_CAP)      # one probe is a noisy estimate: a decade, capped
-    ltol = max(1e-3, 10 * ptol)
-    # steps 1-2 are evaluated at x0 and x0 - t*g1: no curvature estimate involved yet, so every
-    # fixture - chaotic or not - must match the reference there at the plain 1e-4
-    first = min(2, upto)
-    dev_first = float(np.abs(np.asarray(history["total_loss"][:first]) / ref_total[:first] - 1.0).max())
-    record_parity(name, f"total loss, first {first} steps (rel)", dev_first, 1e-4)
-    np.testing.assert_allclose(history["total_loss"][:first], ref_total[:first], rtol=1e-4)
-    dev_loss = float(np.abs(np.asarray(history["total_loss"][:upto]) / ref_total[:upto] - 1.0).max())
-    record_parity(name, f"total loss, {upto} steps (rel)", dev_loss, ltol,
-                  "chaotic fixture: self-spread probe engaged" if probed else "")
-    np.testing.assert_allclose(history["total_loss"][:upto], ref_total[:upto], rtol=ltol)
-    # the two terms: relative, with an absolute floor of 1e-6 of the total for a weighted term that
-    # is numerically negligible in it (the content loss of a content-initialised image is ~1e-5 of
-    # the total and moves by a percent under last-bit changes of the gradient)
-    for key, wgt in (("style_loss", m["style_w"]), ("content_loss", m["content_w"])):
-        np.testing.assert_allclose(wgt * np.asarray(history[key][:upto]), wgt * case.arrays[key][:upto], rtol=ltol,
-                                   atol=1e-6 * float(np.abs(ref_total[:upto]).max()))
-    if not len(blown):
-        note = (f"1e-4 / fixture sensitivity gives {base_tol:.1e}; widened by the self-spread probe (cap {PROBE_TOL_CAP:g})"
-                if probed else ("meets north_star 1e-4 outright" if ptol <= 1e-4 else
-                                f"fixture sensitivity (reference's own spread) {ptol / 4:.1e} x4"))
-        record_parity(name, "x_final per pixel (of range)", dev, ptol, note)
-        assert dev <= ptol, f"final image deviates by {dev:.2e} of its range (tolerance {ptol:.2e})"
+    # Tolerances.  Losses: steps 1-2 are evaluated at x0 and x0 - t*g1 (no curvature estimate involved yet), so
+    # every fixture - chaotic or not - must match the reference there at the plain 1e-4; later steps 1e-3, or ten
+    # times the fixture's per-pixel tolerance where its trajectory amplifies rounding noise, NEVER above 1e-2.
+    # Images: north_star's 1e-4 per pixel, widened to 4x the spread the REFERENCE arithmetic shows for that image
+    # under 2-ulp gradient noise (oracle/make_golden.py); an image whose tolerance would exceed 5e-2 of its range
+    # says nothing and is reported, not compared.  Fixtures with a chaotic or overshooting trajectory store the
+    # image after EVERY step, so they are pinned wherever the reference itself is reproducible (e.g. before and
+    # AFTER the overshoot of mini_clamp_lbfgs / tiny_taps_lbfgs: 5.6e8 -> 8.3e29 -> 5.6e8).
+    ltol = min(max(1e-3, 10 * case.pixel_tolerance()), LOSS_TOL_CAP)
+    if "x_steps" in case.arrays:
+        assert np.array_equal(case.arrays["x_steps"][-1], case.arrays["x_final"])
+        images = [(f"image after step {k + 1} per pixel (of range)", snaps[k], case.arrays["x_steps"][k],
+                   float(case.arrays["x_steps_sensitivity"][k])) for k in range(steps)]
     else:
-        record_parity(name, "x_final per pixel (of range)", float("nan"), float("nan"),
-                      f"reference trajectory overshoots at step {upto}: compared up to there only")
+        images = [("x_final per pixel (of range)", out.detach().cpu(), case.arrays["x_final"],
+                   float(case.arrays["x_final_sensitivity"]))]
+
+    def check(ref_hist: dict, ref_images: list, what: str) -> list[str]:
+        """Compare losses and images with one reference run; returns the failures (empty: all within tolerance)."""
+        bad = []
+        ref_total = np.asarray(ref_hist["total_loss"])
+        first = min(2, steps)
+        dev_first = float(np.abs(np.asarray(history["total_loss"][:first]) / ref_total[:first] - 1.0).max())
+        record_parity(name, f"total loss, first {first} steps (rel){what}", dev_first, 1e-4)
+        if dev_first > 1e-4:
+            bad.append(f"first-step losses {dev_first:.2e}")
+        dev_loss = float(np.abs(np.asarray(history["total_loss"]) / ref_total - 1.0).max())
+        record_parity(name, f"total loss, {steps} steps (rel){what}", dev_loss, ltol)
+        if dev_loss > ltol:
+            bad.append(f"losses {dev_loss:.2e} > {ltol:.1e}")
+        # the two terms: relative, with an absolute floor of 1e-6 of the total for a weighted term that is
+        # numerically negligible in it (the content loss of a content-initialised image is ~1e-5 of the total)
+        for key, wgt in (("style_loss", m["style_w"]), ("content_loss", m["content_w"])):
+            got, ref = wgt * np.asarray(history[key]), wgt * np.asarray(ref_hist[key])
+            if not np.allclose(got, ref, rtol=ltol, atol=1e-6 * float(np.abs(ref_total).max())):
+                bad.append(f"{key} differs")
+        compared = 0
+        for (tag, got, _, sens), ref in zip(images, ref_images, strict=True):
+            scale = float(np.abs(ref).max())
+            dev = float(np.abs(got.numpy() - ref).max() / scale)
+            tol = max(1e-4, 4.0 * sens)
+            if not np.isfinite(tol) or tol > PIXEL_TOL_CAP:
+                record_parity(name, tag + what, dev, float("nan"),
+                              f"reported only: the reference's own spread here is {sens:.1e} of the range (x4 > {PIXEL_TOL_CAP:g})")
+                continue
+            compared += 1
+            record_parity(name, tag + what, dev, tol,
+                          "meets north_star 1e-4 outright" if tol <= 1e-4 else f"reference's own spread {sens:.1e} x4")
+            if dev > tol:
+                bad.append(f"{tag}: {dev:.2e} > {tol:.2e}")
+        if compared == 0:
+            bad.append("no image of this fixture could be compared")
+        return bad
+
+    golden_hist = {k: case.arrays[k] for k in ("total_loss", "style_loss", "content_loss")}
+    bad = check(golden_hist, [ref for _, _, ref, _ in images], "")
+    if not bad:
+        return
+    # ---- Not within tolerance of the stored trajectory.  The one legitimate cause is a ReLU / max-pool near-tie
+    # that the two fp32 evaluations decide differently (tests/parity_util.py) - from there on the trajectories
+    # are on different branches of a piecewise-linear network and nothing bounds their distance.  Checked, not
+    # assumed: (1) up to the first step where decisions differ the plain comparison must hold; (2) the decisions
+    # that differ there must be few and genuine float64 near-ties; (3) the oracle REPLAYED with the HIP path's
+    # decisions imposed at every step must reproduce this run's losses and images within the same tolerances.
+    from oracle import optim_ref
+    nl = pu.n_program_layers(m["style_layers"], m["content_layers"])
+    content, style = case.images()
+    oracle = ocm.OracleModel(ocm.vgg_program(case.weights(), case.cfg), m["style_layers"], m["content_layers"])
+    oracle.set_targets(style, content)
+    x0 = case.tensor("x0")
+    kw = dict(optimizer=m["optimizer"], lr=m["adam_lr"] if m["optimizer"] == "adam" else None, keep_steps=True)
+    free = optim_ref.run_loop(lambda xx: ocm.loss_and_grad(oracle, xx, m["style_w"], m["content_w"]), x0, steps, **kw)
+    evaluated = [x0] + free["x_steps"][:-1]               # the image step k + 1 of the free-running oracle evaluates
+    first_flip = None
+    for k in range(steps):
+        d_ref = pu.oracle_decisions(oracle.program, evaluated[k], nl)
+        flips = pu.count_flips(decisions[k], d_ref)
+        if flips:
+            prog64 = ocm.vgg_program([(w.double(), b.double()) for w, b in case.weights()], case.cfg)
+            gap = pu.flip_gaps(decisions[k], d_ref, prog64, evaluated[k].double(), nl)
+            first_flip = (k + 1, flips, gap)
+            break
+    assert first_flip is not None, f"{name}: {bad} - and no ReLU/pool decision differs from the reference's"
+    step_f, flips, gap = first_flip
+    assert flips <= 16 and gap < 1e-5, f"{name}: step {step_f}: {flips} decisions differ, float64 gap {gap:.2e} of the layer rms"
+    # (1): the loss is continuous across a near-tie, so up to and including the step of the first flip the stored
+    # trajectory's losses must still be matched
+    upto = np.asarray(history["total_loss"][:step_f]) / case.arrays["total_loss"][:step_f] - 1.0
+    assert float(np.abs(upto).max()) <= ltol, f"{name}: losses differ from the reference before any decision does"
+    calls = []
+
+    def locked_eval(xx):
+        k = len(calls)
+        calls.append(k)
+        return ocm.loss_and_grad(pu.lock(oracle, decisions[k]), xx, m["style_w"], m["content_w"])
+    replay = optim_ref.run_loop(locked_eval, x0, steps, **kw)
+    rep_hist = {"total_loss": replay["history"]["total"], "style_loss": replay["history"]["style"],
+                "content_loss": replay["history"]["content"]}
+    rep_images = [xs.numpy() for xs in replay["x_steps"]] if "x_steps" in case.arrays else [replay["x"].numpy()]
+    note = (f" [reference replayed on the HIP path's branch: at step {step_f} {flips} ReLU/pool decision(s) differ, "
+            f"float64 gap <= {gap:.1e} of the layer rms]")
+    bad2 = check(rep_hist, rep_images, note)
+    assert not bad2, f"{name}: differs from the reference even on its own branch: {bad2} (plain comparison: {bad})"
 
 
-PROBE_TOL_CAP = 1e-2
+LOSS_TOL_CAP = 1e-2
+PIXEL_TOL_CAP = 5e-2
 
 
 def request_name(case: GoldenCase) -> str:
