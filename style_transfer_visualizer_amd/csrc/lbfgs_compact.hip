@@ -43,10 +43,12 @@ struct CWs {
   float* prev_g;
   float* S;
   float* Y;
-  float* SY;      // [S][S] by ring slot
-  float* YY;      // [S][S]
+  double* SY;     // [S][S] by ring slot.  Double: an inner product of two fp32 vectors can exceed the fp32 range
+  double* YY;     // [S][S]  (y.y of a step that overshot by 20 orders of magnitude is ~1e53 - torch's vector
+                  // recursion never forms that number, the table form must be able to hold it)
   double* dots;   // [5*MAX_HIST + NSCAL]
-  float* part;    // [5*hist + NSCAL][nparts]
+  double* partd;  // [NSCAL][nparts]  per-wave partial sums of the step's scalars
+  double* part;   // [5*hist][nparts] per-wave partial sums of the history products
 };
 
 __host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -68,11 +70,12 @@ inline CWs carve(void* workspace, size_t n, int hist, int nparts) {
   w.prev_g = p; p += nn;
   w.S = p; p += nn * S;
   w.Y = p; p += nn * S;
-  w.SY = p; p += align_up((size_t)S * S, 64);
-  w.YY = p; p += align_up((size_t)S * S, 64);
-  w.dots = reinterpret_cast<double*>(p); p += 2 * align_up(5 * (size_t)MAX_HIST + NSCAL, 64);
-  w.part = p;
-  (void)nparts;
+  double* q = reinterpret_cast<double*>(p);         // (nn is a multiple of 4096 floats: 8-byte aligned)
+  w.SY = q; q += align_up((size_t)S * S, 64);
+  w.YY = q; q += align_up((size_t)S * S, 64);
+  w.dots = q; q += align_up(5 * (size_t)MAX_HIST + NSCAL, 64);
+  w.partd = q; q += align_up((size_t)NSCAL * nparts, 64);
+  w.part = q;
   return w;
 }
 
@@ -107,7 +110,12 @@ __global__ __launch_bounds__(256) void pass_a_kernel(const float* __restrict__ g
   float* __restrict__ yc = w.Y + (size_t)cslot * nn;
   float* __restrict__ sc = w.S + (size_t)cslot * nn;
   f32x4 gv[U], sv[U], yv[U];
-  float gmax = 0.f, gl1 = 0.f, gg = 0.f, gs = 0.f, gy = 0.f, sy = 0.f, yy = 0.f;
+  // The step's own scalars are summed in double from the start: g.g and y.y overflow fp32 when a step
+  // overshoots (the reference's L-BFGS has no line search: 5.6e8 -> 8.3e29 in tests/golden/mini_clamp_lbfgs),
+  // torch's vector recursion survives that (its y.y = inf only makes H_diag 0) and so must this one -
+  // an inf here would turn into 0 * inf = NaN in the coefficient recursion.
+  float gmax = 0.f;
+  double gl1 = 0.0, gg = 0.0, gs = 0.0, gy = 0.0, sy = 0.0, yy = 0.0;
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const size_t idx = base + (size_t)(u * 256 + tid) * 4;
@@ -119,17 +127,21 @@ __global__ __launch_bounds__(256) void pass_a_kernel(const float* __restrict__ g
       yv[u][e] = gv[u][e] - pg[e];
       sv[u][e] = dv[e] * t;
       gmax = fmaxf(gmax, fabsf(gv[u][e]));
-      gl1 += fabsf(gv[u][e]);
     }
     if (pgrp == 0) {
       *reinterpret_cast<f32x4*>(yc + idx) = yv[u];
       *reinterpret_cast<f32x4*>(sc + idx) = sv[u];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const double gd = (double)gv[u][e], sd = (double)sv[u][e], yd = (double)yv[u][e];
+        gl1 += fabs(gd);
+        gg = fma(gd, gd, gg);
+        gs = fma(gd, sd, gs);
+        gy = fma(gd, yd, gy);
+        sy = fma(sd, yd, sy);
+        yy = fma(yd, yd, yy);
+      }
     }
-    gg += dot4(gv[u], gv[u]);
-    gs += dot4(gv[u], sv[u]);
-    gy += dot4(gv[u], yv[u]);
-    sy += dot4(sv[u], yv[u]);
-    yy += dot4(yv[u], yv[u]);
   }
   const int p = tile_idx * 4 + wave;
   const int per = (m + pgroups - 1) / pgroups;
@@ -138,40 +150,40 @@ __global__ __launch_bounds__(256) void pass_a_kernel(const float* __restrict__ g
     const int slot = (head + jj) % S;
     const float* __restrict__ sj = w.S + (size_t)slot * nn;
     const float* __restrict__ yj = w.Y + (size_t)slot * nn;
-    // two-lane accumulators: v_pk_fma_f32 does the even and the odd elements in one issue slot
-    // (100 scalar FMAs / adds per pair and wave become 40 packed ones)
-    pk2 p0 = {0.f, 0.f}, p1 = {0.f, 0.f}, p2 = {0.f, 0.f}, p3 = {0.f, 0.f}, p4 = {0.f, 0.f};
+    // Double accumulators: a product of two fp32 history / gradient vectors can leave the fp32 range (a step
+    // that overshot leaves y ~ 1e25 in the history: y_j . y_c ~ 1e50), and torch's vector recursion - which
+    // never forms these inner products - stays finite there.  A product of two floats is exact in double.
+    // The sweep stays bandwidth-bound (8 bytes per element and pair beside 5 DP FMAs + conversions).
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const size_t idx = base + (size_t)(u * 256 + tid) * 4;
       const f32x4 s4 = *reinterpret_cast<const f32x4*>(sj + idx);
       const f32x4 y4 = *reinterpret_cast<const f32x4*>(yj + idx);
-      const pk2 sl = {s4[0], s4[1]}, sh = {s4[2], s4[3]}, yl = {y4[0], y4[1]}, yh = {y4[2], y4[3]};
-      const pk2 gl = {gv[u][0], gv[u][1]}, gh = {gv[u][2], gv[u][3]};
-      const pk2 cl = {yv[u][0], yv[u][1]}, ch = {yv[u][2], yv[u][3]};
-      const pk2 dl = {sv[u][0], sv[u][1]}, dh = {sv[u][2], sv[u][3]};
-      p0 = __builtin_elementwise_fma(sh, gh, __builtin_elementwise_fma(sl, gl, p0));   // s_j . g
-      p1 = __builtin_elementwise_fma(yh, gh, __builtin_elementwise_fma(yl, gl, p1));   // y_j . g
-      p2 = __builtin_elementwise_fma(sh, ch, __builtin_elementwise_fma(sl, cl, p2));   // s_j . y_c
-      p3 = __builtin_elementwise_fma(yh, dh, __builtin_elementwise_fma(yl, dl, p3));   // y_j . s_c
-      p4 = __builtin_elementwise_fma(yh, ch, __builtin_elementwise_fma(yl, cl, p4));   // y_j . y_c
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const double sd = (double)s4[e], yd = (double)y4[e];
+        const double gd = (double)gv[u][e], cd = (double)yv[u][e], dd = (double)sv[u][e];
+        a0 = fma(sd, gd, a0);   // s_j . g
+        a1 = fma(yd, gd, a1);   // y_j . g
+        a2 = fma(sd, cd, a2);   // s_j . y_c
+        a3 = fma(yd, dd, a3);   // y_j . s_c
+        a4 = fma(yd, cd, a4);   // y_j . y_c
+      }
     }
-    float a0 = p0[0] + p0[1], a1 = p1[0] + p1[1], a2 = p2[0] + p2[1], a3 = p3[0] + p3[1], a4 = p4[0] + p4[1];
-    // DPP reductions: with ds_bpermute butterflies the 5 x 6 LDS round trips per pair were 6 % of
-    // the sweep at 1024^2
-    a0 = wave_sum_dpp(a0); a1 = wave_sum_dpp(a1); a2 = wave_sum_dpp(a2); a3 = wave_sum_dpp(a3); a4 = wave_sum_dpp(a4);
+    a0 = wave_sum_d_dpp(a0); a1 = wave_sum_d_dpp(a1); a2 = wave_sum_d_dpp(a2); a3 = wave_sum_d_dpp(a3); a4 = wave_sum_d_dpp(a4);
     if (lane == 0) {
-      float* o = w.part + (size_t)(jj * 5) * nparts + p;
+      double* o = w.part + (size_t)(jj * 5) * nparts + p;
       o[0] = a0; o[(size_t)nparts] = a1; o[(size_t)2 * nparts] = a2; o[(size_t)3 * nparts] = a3;
       o[(size_t)4 * nparts] = a4;
     }
   }
   if (pgrp != 0) return;
   gmax = wave_max(gmax);
-  gl1 = wave_sum(gl1); gg = wave_sum(gg); gs = wave_sum(gs); gy = wave_sum(gy); sy = wave_sum(sy); yy = wave_sum(yy);
+  gl1 = wave_sum_d(gl1); gg = wave_sum_d(gg); gs = wave_sum_d(gs); gy = wave_sum_d(gy); sy = wave_sum_d(sy); yy = wave_sum_d(yy);
   if (lane == 0) {
-    float* o = w.part + (size_t)(5 * hist) * nparts + p;
-    o[0] = gmax; o[(size_t)nparts] = gl1; o[(size_t)2 * nparts] = gg; o[(size_t)3 * nparts] = gs;
+    double* o = w.partd + p;
+    o[0] = (double)gmax; o[(size_t)nparts] = gl1; o[(size_t)2 * nparts] = gg; o[(size_t)3 * nparts] = gs;
     o[(size_t)4 * nparts] = gy; o[(size_t)5 * nparts] = sy; o[(size_t)6 * nparts] = yy;
   }
 }
@@ -184,11 +196,12 @@ __global__ __launch_bounds__(256) void reduce_kernel(const CState* st, CWs w, in
   const bool scalar = dot >= 5 * m;
   if (scalar) dot = 5 * hist + (dot - 5 * m);
   if (dot >= 5 * hist + NSCAL) return;
-  const float* __restrict__ src = w.part + (size_t)dot * nparts;
+  const double* __restrict__ src = w.part + (size_t)dot * nparts;                       // history products
+  const double* __restrict__ srcd = w.partd + (size_t)(scalar ? dot - 5 * hist : 0) * nparts;   // the step's scalars
   const bool is_max = dot == 5 * hist;
   double acc = 0.0;
   for (int i = threadIdx.x; i < nparts; i += 256) {
-    const double v = (double)src[i];
+    const double v = scalar ? srcd[i] : src[i];
     acc = is_max ? fmax(acc, v) : acc + v;
   }
   red[threadIdx.x] = acc;
@@ -215,11 +228,12 @@ __global__ __launch_bounds__(256) void solve_kernel(CState* st, CWs w, int hist,
                                                     float tol_change) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int S = hist + 1;
-  // [m][m] tables in logical order; the odd row pitch makes both the column walk of the first
-  // loop and the row walks of the other two free of bank conflicts
+  // ONE [m][m] double table in logical order holds both products: T[i][j] = s_i.y_j for i < j (the recursion
+  // only ever uses s_i.y_j of an OLDER s with a NEWER y) and T[i][j] = y_i.y_j for i >= j (symmetric: the
+  // entry above the diagonal is read from its mirror image) - two double tables would not fit the 160 KB of
+  // LDS at history 100.  The odd row pitch keeps row walks across lanes and column walks free of bank conflicts.
   const int P = hist | 1;
-  float* sSY = reinterpret_cast<float*>(smem_raw);
-  float* sYY = sSY + (size_t)hist * P;
+  double* sT = reinterpret_cast<double*>(smem_raw);
   __shared__ int sh_skip, sh_pushed, sh_m, sh_head, sh_cslot, sh_mold;
   __shared__ float sh_newro, sh_H;
   __shared__ double sh_gs[MAX_S], sh_gy[MAX_S], sh_ro[MAX_S];
@@ -288,15 +302,15 @@ __global__ __launch_bounds__(256) void solve_kernel(CState* st, CWs w, int hist,
   if (sh_pushed) {
     for (int jj = tid; jj < m_old; jj += 256) {
       const int slot = (old_head + jj) % S;
-      const float s_j_yc = (float)D[jj * 5 + 2], y_j_sc = (float)D[jj * 5 + 3], y_j_yc = (float)D[jj * 5 + 4];
+      const double s_j_yc = D[jj * 5 + 2], y_j_sc = D[jj * 5 + 3], y_j_yc = D[jj * 5 + 4];
       w.SY[(size_t)slot * S + cslot] = s_j_yc;     // s_j . y_c
       w.SY[(size_t)cslot * S + slot] = y_j_sc;     // s_c . y_j
       w.YY[(size_t)slot * S + cslot] = y_j_yc;
       w.YY[(size_t)cslot * S + slot] = y_j_yc;
     }
     if (tid == 0) {
-      w.SY[(size_t)cslot * S + cslot] = (float)ys;
-      w.YY[(size_t)cslot * S + cslot] = (float)yy;
+      w.SY[(size_t)cslot * S + cslot] = ys;
+      w.YY[(size_t)cslot * S + cslot] = yy;
     }
   }
   // g-dots in (new) logical order; the pushed pair is the newest logical index m-1
@@ -316,34 +330,28 @@ __global__ __launch_bounds__(256) void solve_kernel(CState* st, CWs w, int hist,
   __syncthreads();
   SOLVE_STAMP(2);
   {
-    // table fill: thread = (row parity, column), sixteen rows of loads in flight per thread (walking
-    // the rows one load at a time made this fill, not the recursion, the longest part of the kernel).
-    // The recursion only ever uses SY entries with row < column (s_i.y_j of an OLDER s with a NEWER
-    // y), so the rest of sSY is stored as zero and the walks below need no per-entry guards.
+    // table fill: thread = (row parity, column), a batch of rows of loads in flight per thread (walking the
+    // rows one load at a time made this fill, not the recursion, the longest part of the kernel)
     const int j = tid & 127, i0 = tid >> 7;
     if (j < m) {
       int col = head + j;
       if (col >= S) col -= S;
-      constexpr int FB = 50;                   // rows per batch: 2 x FB loads in flight, then the stores
+      constexpr int FB = 25;                   // rows per batch: FB loads in flight, then the stores
       for (int ib = i0; ib < m; ib += 2 * FB) {
-        float vs[FB], vy[FB];
+        double v[FB];
 #pragma unroll
         for (int k = 0; k < FB; ++k) {
           int i = ib + 2 * k;
           if (i >= m) i = m - 1;               // clamped, not branched: keeps the batch one burst of loads
           int rs = head + i;
           if (rs >= S) rs -= S;
-          const size_t src = (size_t)rs * S + col;
-          vs[k] = w.SY[src];
-          vy[k] = w.YY[src];
+          const double* __restrict__ src = (i < j) ? w.SY : w.YY;
+          v[k] = src[(size_t)rs * S + col];
         }
 #pragma unroll
         for (int k = 0; k < FB; ++k) {
           const int i = ib + 2 * k;
-          if (i < m) {
-            sSY[i * P + j] = (i < j) ? vs[k] : 0.0f;
-            sYY[i * P + j] = vy[k];
-          }
+          if (i < m) sT[i * P + j] = v[k];
         }
       }
     }
@@ -388,20 +396,26 @@ __global__ __launch_bounds__(256) void solve_kernel(CState* st, CWs w, int hist,
   auto walk1 = [&](auto HI, int ifrom, int ito) {
     constexpr bool hi = decltype(HI)::value;
     if (ifrom < ito) return;
-    float n0[CH], n1[CH];
-    auto fetch = [&](int ib) {                 // column entries SY[own][ib - k] (zero unless own < i)
+    double n0[CH], n1[CH];
+    auto fetch = [&](int ib) {                 // column entries s_own . y_i, zero unless own < i
 #pragma unroll
       for (int k = 0; k < CH; ++k) {
         const int i = max(ib - k, 0);
-        n0[k] = sSY[r0 + i];
-        if (hi) n1[k] = sSY[r1 + i];           // below 64 no slot-1 index is older than i
+        const double v0 = sT[r0 + i];
+        if (hi) {                              // i >= 64: every slot-0 index is older than i
+          n0[k] = v0;
+          const double v1 = sT[r1 + i];
+          n1[k] = (j1 < i) ? v1 : 0.0;
+        } else {                               // below 64 no slot-1 index is older than i
+          n0[k] = (j0 < i) ? v0 : 0.0;
+        }
       }
     };
     fetch(ifrom);
     for (int ib = ifrom; ib >= ito; ib -= CH) {
-      float c0[CH], c1[CH];
+      double c0[CH], c1[CH];
 #pragma unroll
-      for (int k = 0; k < CH; ++k) { c0[k] = n0[k]; c1[k] = hi ? n1[k] : 0.0f; }
+      for (int k = 0; k < CH; ++k) { c0[k] = n0[k]; c1[k] = hi ? n1[k] : 0.0; }
       if (ib - CH >= ito) fetch(ib - CH);
 #pragma unroll
       for (int k = 0; k < CH; ++k) {
@@ -413,8 +427,8 @@ __global__ __launch_bounds__(256) void solve_kernel(CState* st, CWs w, int hist,
         if (lane == src) {
           if (hi) { al1 = al; cy1 = -al; } else { al0 = al; cy0 = -al; }
         }
-        a0 -= al * (double)c0[k];
-        if (hi) a1 -= al * (double)c1[k];
+        a0 -= al * c0[k];
+        if (hi) a1 -= al * c1[k];
       }
     }
   };
@@ -430,18 +444,18 @@ __global__ __launch_bounds__(256) void solve_kernel(CState* st, CWs w, int hist,
   auto walk2 = [&](auto HI, int jfrom, int jto) {       // j = jfrom .. jto-1
     constexpr bool hi = decltype(HI)::value;
     if (jfrom >= jto) return;
-    float n0[CH], n1[CH];
-    auto fetch = [&](int jb) {
+    double n0[CH], n1[CH];
+    auto fetch = [&](int jb) {                 // y_own . y_j: stored at [max(own, j)][min(own, j)]
 #pragma unroll
       for (int k = 0; k < CH; ++k) {
         const int j = min(jb + k, m - 1);
-        n0[k] = sYY[r0 + j];
-        n1[k] = sYY[r1 + j];
+        n0[k] = sT[(j <= q0) ? r0 + j : j * P + q0];
+        n1[k] = sT[(j <= q1) ? r1 + j : j * P + q1];
       }
     };
     fetch(jfrom);
     for (int jb = jfrom; jb < jto; jb += CH) {
-      float c0[CH], c1[CH];
+      double c0[CH], c1[CH];
 #pragma unroll
       for (int k = 0; k < CH; ++k) { c0[k] = n0[k]; c1[k] = n1[k]; }
       if (jb + CH < jto) fetch(jb + CH);
@@ -450,8 +464,8 @@ __global__ __launch_bounds__(256) void solve_kernel(CState* st, CWs w, int hist,
         const int j = jb + k;
         if (j >= jto) break;
         const double cyj = bcast(hi ? cy1 : cy0, hi ? j - 64 : j);
-        b0 += cyj * (double)c0[k];
-        b1 += cyj * (double)c1[k];
+        b0 += cyj * c0[k];
+        b1 += cyj * c1[k];
       }
     }
   };
@@ -474,20 +488,26 @@ __global__ __launch_bounds__(256) void solve_kernel(CState* st, CWs w, int hist,
   auto walk3 = [&](auto HI, int ifrom, int ito) {       // i = ifrom .. ito-1
     constexpr bool hi = decltype(HI)::value;
     if (ifrom >= ito) return;
-    float n0[CH], n1[CH];
-    auto fetch = [&](int ib) {                 // row entries SY[ib + k][own] (zero unless own > i)
+    double n0[CH], n1[CH];
+    auto fetch = [&](int ib) {                 // row entries s_i . y_own, zero unless own > i
 #pragma unroll
       for (int k = 0; k < CH; ++k) {
         const int i = min(ib + k, m - 1);
-        if (!hi) n0[k] = sSY[i * P + q0];      // from 64 on no slot-0 index is newer than i
-        n1[k] = sSY[i * P + q1];
+        const double v1 = sT[i * P + q1];
+        if (!hi) {                             // i < 64: every slot-1 index is newer than i
+          const double v0 = sT[i * P + q0];
+          n0[k] = (j0 > i) ? v0 : 0.0;
+          n1[k] = v1;
+        } else {                               // from 64 on no slot-0 index is newer than i
+          n1[k] = (j1 > i) ? v1 : 0.0;
+        }
       }
     };
     fetch(ifrom);
     for (int ib = ifrom; ib < ito; ib += CH) {
-      float c0[CH], c1[CH];
+      double c0[CH], c1[CH];
 #pragma unroll
-      for (int k = 0; k < CH; ++k) { c0[k] = hi ? 0.0f : n0[k]; c1[k] = n1[k]; }
+      for (int k = 0; k < CH; ++k) { c0[k] = hi ? 0.0 : n0[k]; c1[k] = n1[k]; }
       if (ib + CH < ito) fetch(ib + CH);
 #pragma unroll
       for (int k = 0; k < CH; ++k) {
@@ -500,8 +520,8 @@ __global__ __launch_bounds__(256) void solve_kernel(CState* st, CWs w, int hist,
         if (lane == src) {
           if (hi) cs1 = csi; else cs0 = csi;
         }
-        if (!hi) b0 += csi * (double)c0[k];
-        b1 += csi * (double)c1[k];
+        if (!hi) b0 += csi * c0[k];
+        b1 += csi * c1[k];
       }
     }
   };
@@ -597,8 +617,10 @@ extern "C" size_t stv_lbfgsc_workspace_bytes(size_t n, int history) {
   const int S = history + 1;
   const int tile = tile_floats(n);
   const size_t nparts = (nn / tile) * 4;
-  size_t floats = nn * (2 + 2 * (size_t)S) + 2 * align_up((size_t)S * S, 64) +
-                  2 * 2 * align_up(5 * (size_t)MAX_HIST + NSCAL, 64) + (5 * (size_t)history + NSCAL) * nparts + 64;
+  // (two floats per double: the two product tables, the inner-product block, the scalars' partial sums)
+  size_t floats = nn * (2 + 2 * (size_t)S) + 2 * 2 * align_up((size_t)S * S, 64) +
+                  2 * align_up(5 * (size_t)MAX_HIST + NSCAL, 64) + 2 * align_up((size_t)NSCAL * nparts, 64) +
+                  2 * 5 * (size_t)history * nparts + 64;
   return floats * sizeof(float);
 }
 
@@ -652,8 +674,8 @@ extern "C" int stv_lbfgsc_apply(float* x, const float* grad, void* state, void* 
   hipStream_t st = static_cast<hipStream_t>(stream);
   CState* s = static_cast<CState*>(state);
   const StepGeom g = step_geom(workspace, n, history);
-  const size_t lds = 2 * (size_t)history * (size_t)(history | 1) * sizeof(float);
-  if (stv_set_max_lds(reinterpret_cast<const void*>(&solve_kernel), 2 * MAX_HIST * (MAX_HIST | 1) * (int)sizeof(float)) != STV_OK)
+  const size_t lds = (size_t)history * (size_t)(history | 1) * sizeof(double);
+  if (stv_set_max_lds(reinterpret_cast<const void*>(&solve_kernel), MAX_HIST * (MAX_HIST | 1) * (int)sizeof(double)) != STV_OK)
     return STV_ERR_LAUNCH;
   hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(256), lds, st, s, g.w, history, lr, tol_grad, tol_change);
   // A/B aid: STV_LBFGS_ACC=f32 restores the fp32 accumulation of the direction (less accurate, see pass_b_kernel)
@@ -678,7 +700,7 @@ extern "C" size_t stv_lbfgsc_dots_offset(size_t n, int history, int* count, int*
   const int S = history + 1;
   if (count) *count = 5 * MAX_HIST + NSCAL;
   if (max_index) *max_index = 5 * MAX_HIST;
-  return (nn * (2 + 2 * (size_t)S) + 2 * align_up((size_t)S * S, 64)) * sizeof(float);
+  return (nn * (2 + 2 * (size_t)S) + 2 * 2 * align_up((size_t)S * S, 64)) * sizeof(float);
 }
 
 extern "C" int stv_lbfgsc_step(float* x, const float* grad, void* state, void* workspace, size_t n, int history,

@@ -136,6 +136,28 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
 #undef STV_DPP_ADD
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// The same DPP ladder for a double: the two halves travel as 32-bit DPP moves (a masked-out row receives
+// 0.0), the addition is one DP add per step - no LDS round trips (wave_sum_d below costs 12 ds_bpermute).
+__device__ __forceinline__ double wave_sum_d_dpp(double v) {
+#define STV_DPP_ADD_D(ctrl, rows)                                                                         \
+  do {                                                                                                  \
+    const long long b_ = __double_as_longlong(v);                                                       \
+    const int lo_ = __builtin_amdgcn_update_dpp(0, (int)(b_ & 0xFFFFFFFFll), ctrl, rows, 0xF, false);    \
+    const int hi_ = __builtin_amdgcn_update_dpp(0, (int)(b_ >> 32), ctrl, rows, 0xF, false);             \
+    v += __longlong_as_double(((long long)hi_ << 32) | (unsigned int)lo_);                              \
+  } while (0)
+  STV_DPP_ADD_D(0xB1, 0xF);
+  STV_DPP_ADD_D(0x4E, 0xF);
+  STV_DPP_ADD_D(0x141, 0xF);
+  STV_DPP_ADD_D(0x140, 0xF);
+  STV_DPP_ADD_D(0x142, 0xA);
+  STV_DPP_ADD_D(0x143, 0xC);
+#undef STV_DPP_ADD_D
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFll), 63);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

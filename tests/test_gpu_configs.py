@@ -59,7 +59,7 @@ def test_config_runs_at_full_length(size, steps, every, precision, monkeypatch):
     # losses vs the oracle at the same image.  fp32 (parity mode, the reference's arithmetic): rounding level.
     # bf16: the oracle rounds where the kernels round, but fp32 sums in another order flip ~1e-3 of those
     # roundings (tests/test_gpu_bf16_layerwise.py bounds every stored tensor to one ulp); a bf16 ulp is 4e-3.
-    ltol = 1e-2 if bf16 else 1e-4
+    ltol = 5e-3 if bf16 else 1e-4
     case = f"configs[{1 if size == 512 else 2}] {size}x{size} x{steps} {precision}"
     cfg = stv_config.StyleTransferConfig.model_validate({})
     oc = cfg.optimization
@@ -123,11 +123,26 @@ def test_config_runs_at_full_length(size, steps, every, precision, monkeypatch):
     oracle.set_targets(style, content)
     t1 = time.time()
     worst = 0.0
-    for step, img in sorted(images.items()):
+    def oracle_losses(img):
         with torch.no_grad():
             s_l, c_l = oracle(img)
-        s_ref, c_ref = float(torch.stack(s_l).sum()), float(torch.stack(c_l).sum())
-        t_ref = oc.style_w * s_ref + oc.content_w * c_ref
+        s_v, c_v = float(torch.stack(s_l).sum()), float(torch.stack(c_l).sum())
+        return s_v, c_v, oc.style_w * s_v + oc.content_w * c_v
+    spread_max = 0.0
+    for step, img in sorted(images.items()):
+        s_ref, c_ref, t_ref = oracle_losses(img)
+        tol_k = ltol
+        if bf16:
+            # What does bf16 storage do to ITSELF under a last-bit change of the image?  The rounding-faithful oracle
+            # re-evaluated at img * (1 + 1.2e-7 u): every fp32 sum lands a few ulps elsewhere, some bf16 roundings
+            # flip, and late in the run (losses small, the style score a squared difference of nearly equal Grams)
+            # that moves the losses by up to a percent.  Two correct evaluations cannot agree better than that
+            # spread; the HIP path must agree with the oracle within 4x of it (floor: the plain bf16 tolerance).
+            g = torch.Generator().manual_seed(step)
+            pert = [oracle_losses(img * (1.0 + 1.2e-7 * (2.0 * torch.rand(img.shape, generator=g) - 1.0))) for _ in range(2)]
+            spread = max(abs(p[2] - t_ref) / abs(t_ref) for p in pert)
+            spread_max = max(spread_max, spread)
+            tol_k = max(ltol, 4.0 * spread)
         got = (history["style_loss"][step - 1], history["content_loss"][step - 1], history["total_loss"][step - 1])
         # each weighted term relative to itself - or, once the optimisation has made it a small part of the total
         # (the style score is a squared DIFFERENCE of nearly equal Grams by then, and bf16 rounding flips move it
@@ -137,10 +152,11 @@ def test_config_runs_at_full_length(size, steps, every, precision, monkeypatch):
             rel = abs(a - b) / abs(b)
             if wgt * abs(a - b) > floor:
                 worst = max(worst, rel)
-                assert rel <= ltol, f"{case} step {step}: {nm} loss {a!r} vs oracle at the same image {b!r}"
+                assert rel <= tol_k, f"{case} step {step}: {nm} loss {a!r} vs oracle at the same image {b!r} (tolerance {tol_k:.1e})"
             elif nm == "total":
                 worst = max(worst, rel)
-    record_parity(case, f"losses vs oracle at the same image, {len(images)} steps (rel)", worst, ltol,
+    record_parity(case, f"losses vs oracle at the same image, {len(images)} steps (rel)", worst, max(ltol, 4.0 * spread_max),
+                  (f"bf16 oracle's own spread under a last-bit change of the image: {spread_max:.1e}; " if bf16 else "") +
                   f"steps {sorted(images)}; loss {totals[0]:.3e} -> {totals[-1]:.3e}; {steps / wall:.0f} steps/s incl. test "
                   f"callbacks; oracle {time.time() - t1:.0f} s")
 

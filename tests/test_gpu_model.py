@@ -165,11 +165,11 @@ def test_trajectory_matches_reference(golden_case: GoldenCase, monkeypatch):
         first = min(2, steps)
         dev_first = float(np.abs(np.asarray(history["total_loss"][:first]) / ref_total[:first] - 1.0).max())
         record_parity(name, f"total loss, first {first} steps (rel){what}", dev_first, 1e-4)
-        if dev_first > 1e-4:
+        if not dev_first <= 1e-4:
             bad.append(f"first-step losses {dev_first:.2e}")
         dev_loss = float(np.abs(np.asarray(history["total_loss"]) / ref_total - 1.0).max())
         record_parity(name, f"total loss, {steps} steps (rel){what}", dev_loss, ltol)
-        if dev_loss > ltol:
+        if not dev_loss <= ltol:
             bad.append(f"losses {dev_loss:.2e} > {ltol:.1e}")
         # the two terms: relative, with an absolute floor of 1e-6 of the total for a weighted term that is
         # numerically negligible in it (the content loss of a content-initialised image is ~1e-5 of the total)
@@ -189,7 +189,7 @@ def test_trajectory_matches_reference(golden_case: GoldenCase, monkeypatch):
             compared += 1
             record_parity(name, tag + what, dev, tol,
                           "meets north_star 1e-4 outright" if tol <= 1e-4 else f"reference's own spread {sens:.1e} x4")
-            if dev > tol:
+            if not dev <= tol:                   # (a NaN deviation is a failure)
                 bad.append(f"{tag}: {dev:.2e} > {tol:.2e}")
         if compared == 0:
             bad.append("no image of this fixture could be compared")
