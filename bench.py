@@ -129,8 +129,11 @@ def forward_bytes(sched, dtype_bytes: int) -> float:
     return total
 
 
+HISTORY_SIZE = 100
+
+
 def run_gpu(args, rank: int, world: int, device: torch.device, size: int, steps: int, warmup: int, *,
-            precision: str | None = None, profile: bool = True):
+            precision: str | None = None, profile: bool = True, prefill_history: bool = True):
     """One L-BFGS run of `warmup` untimed + `steps` timed optimisation steps through the real
     OptimizationRunner; returns elapsed seconds of the timed region (+ the kernel breakdown on rank 0)."""
     import torch.distributed as dist
@@ -142,7 +145,13 @@ def run_gpu(args, rank: int, world: int, device: torch.device, size: int, steps:
     os.environ.setdefault("STV_SYNTHETIC_WEIGHTS", "0")
     cfg = stv_config.StyleTransferConfig.model_validate({})
     oc = cfg.optimization
-    oc.steps = warmup + steps
+    # configs[1]/[2] are 300 / 500-step runs with history_size 100: from step 101 on every step sees a FULL
+    # L-BFGS history (two sweeps over 2 x 100 vectors).  That steady state is what `value` rates, whatever
+    # --warmup says: the history is filled by untimed steps first (set-up, like uploading the weights), then W
+    # warm-up steps, then exactly K timed steps.
+    prefill = max(0, HISTORY_SIZE - warmup) if prefill_history else 0
+    warmup_total = prefill + warmup
+    oc.steps = warmup_total + steps
     oc.init_method = "random"
     cfg.hardware.precision = precision
     cfg.video.create_video = False
@@ -165,12 +174,12 @@ def run_gpu(args, rank: int, world: int, device: torch.device, size: int, steps:
         return time.perf_counter()
 
     def on_end(metrics):
-        if metrics.step == warmup:
+        if metrics.step == warmup_total:
             marks["t0"] = fence()
-        elif metrics.step == warmup + steps:
+        elif metrics.step == warmup_total + steps:
             marks["t1"] = fence()
 
-    if warmup == 0:
+    if warmup_total == 0:
         marks["t0"] = fence()
     runner = optimization.OptimizationRunner(
         model, x, cfg, optimizer=opt, progress_bar=_Bar(),
@@ -186,9 +195,29 @@ def run_gpu(args, rank: int, world: int, device: torch.device, size: int, steps:
         gathered = parallel.gather_results([(rank, out.detach().contiguous())], world)
         assert len(gathered) == world and all(g is not None for g in gathered)
 
-    info = {"elapsed": elapsed}
+    info = {"elapsed": elapsed, "prefill": prefill}
     st = opt.device_state() if hasattr(opt, "device_state") else {}
     info["lbfgs"] = {k: st.get(k) for k in ("n_iter", "hist_len", "skip", "no_update")}
+    if rank == 0 and hasattr(opt, "device_state"):
+        # the optimizer update alone, at the history length the timed region ended with: 20 updates with the last
+        # gradient inside one event pair.  Algorithmic bytes: two sweeps over the 2m history vectors + 8 vectors.
+        from style_transfer_visualizer_amd import ops
+        m = int(st.get("hist_len") or 0)
+        n_el = x.numel()
+        xs, gs = x.detach().clone(), x.grad.detach().clone()
+        stream = torch.cuda.Stream(device=device)
+        with torch.cuda.stream(stream):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for k in range(23):
+                if k == 3:
+                    e0.record()
+                ops.lbfgs_step(xs, gs, opt._dev_state, opt._work, HISTORY_SIZE, HISTORY_SIZE, 1.0, compact=opt._compact)
+            e1.record()
+            e1.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        nbytes = (4 * m + 8) * n_el * 4
+        info["lbfgs"].update(bytes=nbytes, ms=round(ms, 4), hbm_frac=round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             note="history read twice per step, exact fp32 pairs: the floor of this term is its HBM time")
     if rank == 0 and profile:
         # per-op device time of the fused step (HIP events on the launch stream), median of 5 passes
         eng = next(iter(model._engines.values()))
@@ -212,15 +241,20 @@ def run_gpu(args, rank: int, world: int, device: torch.device, size: int, steps:
             xin = x.detach()
             fwd_gram_ctx_ms = replay_ms(lambda: eng.forward_losses(xin))
             prog.profile()
-            # every op 8x inside its event pair: an event pair costs as much as a short kernel
-            passes = [prog.profile(reps=8) for _ in range(5)]
+            # Per-op device time IN CONTEXT: every op once, in program order, inside its own event pair - its
+            # operands are where the step leaves them (what `rocprofv3 --kernel-trace` averages over the run's
+            # steps), not cache-hot from a back-to-back repeat.  Median of 7 passes.
+            passes = [prog.profile(reps=1) for _ in range(7)]
+            hot = [prog.profile(reps=8) for _ in range(3)]       # the same ops 8x back to back (cache-hot), for comparison
         # per op the MEDIAN of the passes: one disturbed pass (a clock dip, a neighbour's tail) must not rate a kernel
         ms = [sorted(p[i] for p in passes)[len(passes) // 2] for i in range(prog.n_ops)]
+        ms_hot = [sorted(p[i] for p in hot)[len(hot) // 2] for i in range(prog.n_ops)]
         groups: dict = {}
-        for meta, fl, t in zip(prog.op_meta, prog.op_flags, ms, strict=True):
+        for meta, fl, t, th in zip(prog.op_meta, prog.op_flags, ms, ms_hot, strict=True):
             g = kernel_group(meta, OP, 1 if precision == "bf16" else 0, fl)
-            e = groups.setdefault(g, {"ms": 0.0, "flops": 0.0, "launches": 0})
+            e = groups.setdefault(g, {"ms": 0.0, "ms_hot": 0.0, "flops": 0.0, "launches": 0})
             e["ms"] += t
+            e["ms_hot"] += th
             e["launches"] += 1
             if meta[0] == OP["CONV"]:
                 e["flops"] += conv_flops(meta)
@@ -240,7 +274,9 @@ def run_gpu(args, rank: int, world: int, device: torch.device, size: int, steps:
             "bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": peak,
             "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
             "launches_per_step": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 5),
+            "avg_launch_ms_cache_hot": round(dom["ms_hot"] / dom["launches"], 5),
             "flop_per_launch": dom["flops"] / dom["launches"],
+            "timing": "HIP events around each op of the step program, in program order (operands as the step leaves them)",
         }
         # forward + Gram/content losses = every op up to the score combine (SURVEY.md §8(d) byte model)
         # (timed in context above: replays of the forward-only program; the per-op pass below runs
@@ -311,6 +347,7 @@ def cpu_baseline(size: int, threads: int) -> dict:
     from style_transfer_visualizer_amd import synthetic
 
     torch.set_num_threads(threads)
+    torch.manual_seed(0)
     weights = synthetic.synthetic_conv_weights(0)
     model = ocm.OracleModel(ocm.vgg_program(weights, synthetic.VGG19_CFG), (0, 5, 10, 19, 28), (21,))
     content = synthetic.synthetic_image(0, size, size)
@@ -330,8 +367,42 @@ def cpu_baseline(size: int, threads: int) -> dict:
     for _ in range(timed):
         opt.step(closure)
     dt = time.perf_counter() - t0
-    return {"value": round(timed / dt, 4), "unit": "steps/s", "cores": threads, "kind": "port",
+    return {"value": round(timed / dt, 4), "unit": "steps/s", "cores": threads, "kind": "port", "cpu": host_cpu()["model"],
             "sample": f"{size}x{size} VGG19 fp32, torch-CPU oracle, {warm} warm-up + {timed} timed L-BFGS steps"}
+
+
+def host_cpu() -> dict:
+    """CPU model and the cores this process may use (physical cores, model stated)."""
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        allowed = logical
+    physical = None
+    try:
+        import psutil  # noqa: PLC0415
+        physical = psutil.cpu_count(logical=False)
+    except Exception:  # noqa: BLE001
+        physical = None
+    # one thread per physical core, never more than this process is allowed to run on
+    threads = max(1, min(allowed, physical or allowed))
+    return {"model": model, "logical": logical, "physical": physical, "allowed": allowed, "threads": threads}
+
+
+def _tile_info() -> dict:
+    from style_transfer_visualizer_amd import _lib
+    info = dict(_lib.tile_table_info)
+    info["STV_CONV_TUNE"] = os.environ.get("STV_CONV_TUNE", "unset (table, no measuring)")
+    return info
 
 
 STEADY_FILL, STEADY_STEPS = 100, 60        # history_size = 100: after 100 steps every step runs at m = 100
@@ -341,7 +412,7 @@ def steady_state(args, device: torch.device, size: int, precision: str) -> dict:
     """Throughput of the CONFIG, not of the ramp: BASELINE configs[1]/[2] are 300/500-step runs, so
     >= 2/3 of their steps see a full L-BFGS history (m = 100) whatever --steps/--warmup the caller
     chose for the headline line.  Fills the history with STEADY_FILL untimed steps, times STEADY_STEPS."""
-    e = run_gpu(args, 0, 1, device, size, STEADY_STEPS, STEADY_FILL, precision=precision, profile=False)
+    e = run_gpu(args, 0, 1, device, size, STEADY_STEPS, STEADY_FILL, precision=precision, profile=False, prefill_history=False)
     return {"steps_per_s": round(STEADY_STEPS / e["elapsed"], 2), "ms_per_step": round(1e3 * e["elapsed"] / STEADY_STEPS, 4),
             "hist_len": e["lbfgs"].get("hist_len"), "fill_steps": STEADY_FILL, "timed_steps": STEADY_STEPS,
             "precision": precision}
@@ -421,10 +492,11 @@ def main() -> None:
                  "value": round(k2 / e["elapsed"], 3), "ms_per_step": round(1e3 * e["elapsed"] / k2, 4),
                  "roofline": e.get("roofline"), "fwd_gram": e.get("fwd_gram"), "closure": e.get("closure"),
                  "breakdown_ms": e.get("breakdown_ms"), "lbfgs": e.get("lbfgs")}
-        steady = {"note": ("throughput with the L-BFGS history full (m = 100), independent of --steps/--warmup: "
+        steady = {"note": ("throughput with the L-BFGS history full (m = 100): the headline value and extra_1024 are "
+                           "timed in that state themselves (history prefilled by untimed steps); the fp32 parity mode: "
                            f"{STEADY_FILL} untimed fill steps, then {STEADY_STEPS} timed steps through OptimizationRunner"),
-                  "512x512_bf16": steady_state(args, device, 512, "bf16"),
-                  "1024x1024_bf16": steady_state(args, device, 1024, "bf16"),
+                  "512x512_bf16": {"steps_per_s": round(args.steps / info["elapsed"], 2), "hist_len": info["lbfgs"].get("hist_len")},
+                  "1024x1024_bf16": {"steps_per_s": extra["value"], "hist_len": extra["lbfgs"].get("hist_len")},
                   "512x512_fp32_parity_mode": steady_state(args, device, 512, "fp32")}
 
     if rank == 0:
@@ -448,7 +520,11 @@ def main() -> None:
                              "(BASELINE.json configs[1]); weights: synthetic He-scaled"),
                 "size": args.size, "images": world, "init_method": "random",
                 "style_w": 1e5, "content_w": 1.0, "parallelism": f"replicas x{world} (independent images)",
+                "lbfgs_history_prefill_steps": info.get("prefill", 0),
+                "timed_region": "exactly --steps optimizer steps at a full L-BFGS history (m = 100), after --warmup untimed ones",
+                "world_size": world,
             },
+            "tiles": _tile_info(),
             "roofline": info.get("roofline"),
             "fwd_gram": info.get("fwd_gram"),
             "closure": info.get("closure"),
@@ -460,7 +536,9 @@ def main() -> None:
         if extra is not None:
             line["extra_1024"] = extra
         if world == 1 and not args.no_cpu_baseline:
-            threads = max(1, min(os.cpu_count() or 1, 16))
+            cpu = host_cpu()
+            threads = cpu["threads"]
+            line["host_cpu"] = cpu
             line["cpu_baseline"] = cpu_baseline(args.size, threads)
             if not args.no_extra and args.size == 512:      # the other two sizes beside it
                 line["cpu_baseline_other_sizes"] = {"256x256": cpu_baseline(256, threads),

@@ -107,13 +107,23 @@ int stv_conv_first_fwd_gram(const float* x_nchw, const float* packed, const floa
  * is kept unless another tile is > 3 % faster).  Returns the configuration index
  * (>= 0; the value stv_conv_config reports afterwards), -1 when the shape runs on
  * the direct kernel (nothing to tune), or -(100 + STV_ERR_*) on failure.
- * Synchronises `stream`.  STV_CONV_TUNE=0 in the environment disables measuring.
+ * Synchronises `stream` when it measures: only with STV_CONV_TUNE=1 / 2 in the environment (see the table
+ * functions below); STV_CONV_TUNE=0 ignores the table and pins the analytic choice.
  * Different tiles sum K in different orders: results agree to fp32 rounding, not
  * bit for bit, across configurations.
  * taps = STV_TUNE_ROUTE (bf16): the shape is measured as stv_conv_igemm_route runs it (dgrad + pooling backward in
  * the epilogue, 2H x 2W output) and remembered under its own key - the routed epilogue prefers smaller tiles. */
 #define STV_TUNE_ROUTE 109
 int stv_conv_tune(int H, int W, int cin, int cout, int taps, int dtype, void* stream);
+/* The tile table as data (7 ints per entry: H, W, cin, cout, taps - 9, 1 or STV_TUNE_ROUTE -, element bytes, tile
+ * index).  Measuring only happens with STV_CONV_TUNE=1 (or 2) in the environment; otherwise stv_conv_tune and every
+ * conv launch look a shape up in this table and fall back to the analytic choice.  The host persists measured
+ * tables (conv_tiles_gfx950.json) and imports them at load time, so that a shape runs on the same tile - same
+ * summation order, same kernel name in a profile - in every process.  stv_conv_tune_export returns the number of
+ * entries (and writes up to max_entries of them); stv_conv_tune_import adds / overwrites entries (0 entries: clears
+ * the table), STV_ERR_ARG on a malformed entry. */
+int stv_conv_tune_export(int* out7, int max_entries);
+int stv_conv_tune_import(const int* in7, int n_entries);
 int stv_conv_igemm(const void* x, const void* w, const float* bias, const void* ref,
                    void* y, int H, int W, int cin, int cout, int taps, int flags,
                    int dtype, void* stream);

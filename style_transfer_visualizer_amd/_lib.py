@@ -71,6 +71,8 @@ SIGNATURES = {
     "stv_conv_igemm_dual": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                     c_int, c_int, c_int, c_void_p]),
     "stv_conv_tune": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "stv_conv_tune_export": (c_int, [ctypes.POINTER(c_int), c_int]),
+    "stv_conv_tune_import": (c_int, [ctypes.POINTER(c_int), c_int]),
     "stv_conv_uses_ws": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "stv_conv_config": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "stv_maxpool_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
@@ -127,7 +129,41 @@ def load() -> ctypes.CDLL:
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    _import_tile_table(lib)
     return lib
+
+
+TILE_TABLE_PATH = os.environ.get("STV_TILE_TABLE") or os.path.join(_HERE, "conv_tiles_gfx950.json")
+tile_table_info: dict = {"source": None, "entries": 0}
+
+
+def _import_tile_table(lib: ctypes.CDLL) -> None:
+    """Hand the persisted tile choices (tools/tune_tiles.py, measured on an MI355X) to the library: which tile a
+    conv shape runs on is then the same in every process (results bit-reproducible run to run, kernel names in a
+    profile reproducible).  STV_CONV_TUNE=0 makes the library ignore the table (analytic choice); =1 re-measures
+    shapes the table does not hold.  A missing file is fine: analytic choices."""
+    import json  # noqa: PLC0415
+    if not os.path.exists(TILE_TABLE_PATH):
+        return
+    with open(TILE_TABLE_PATH) as fh:
+        doc = json.load(fh)
+    rows = [int(v) for e in doc.get("entries", []) for v in (e["H"], e["W"], e["cin"], e["cout"], e["taps"], e["elem_bytes"], e["cfg"])]
+    if not rows:
+        return
+    arr = (c_int * len(rows))(*rows)
+    check(lib.stv_conv_tune_import(arr, len(rows) // 7), f"stv_conv_tune_import({TILE_TABLE_PATH})")
+    tile_table_info.update(source=os.path.basename(TILE_TABLE_PATH), entries=len(rows) // 7, measured_on=doc.get("device"),
+                           tool=doc.get("tool"))
+
+
+def export_tile_table() -> list[dict]:
+    """The library's current tile table (imported + measured in this process) as a list of dicts."""
+    lib = load()
+    n = int(lib.stv_conv_tune_export(None, 0))
+    arr = (c_int * (7 * max(n, 1)))()
+    n = min(n, int(lib.stv_conv_tune_export(arr, n)))
+    keys = ("H", "W", "cin", "cout", "taps", "elem_bytes", "cfg")
+    return [dict(zip(keys, (int(arr[7 * i + k]) for k in range(7)), strict=True)) for i in range(n)]
 
 
 def check(rc: int, what: str) -> None:

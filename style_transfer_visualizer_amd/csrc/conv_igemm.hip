@@ -1018,6 +1018,46 @@ extern "C" int stv_conv_uses_ws(int H, int W, int cin, int cout, int taps, int d
   return stv_conv_ws_supported(a, dtype, taps) ? 1 : 0;
 }
 
+// The tile table as data: 7 ints per entry {H, W, cin, cout, taps (9, 1 or STV_TUNE_ROUTE), element bytes, cfg}.
+// Measured choices are PERSISTED by the host (style_transfer_visualizer_amd/conv_tiles_gfx950.json, produced by
+// tools/tune_tiles.py on an MI355X) and imported when the library is loaded: which tile a shape runs on - and with
+// it the summation order of its results and the kernel name a profile shows - is then the same in every run.
+extern "C" int stv_conv_tune_export(int* out7, int max_entries) {
+  std::lock_guard<std::mutex> lk(g_tune_mu);
+  int n = 0;
+  for (const TuneEntry& e : g_tune) {
+    if (out7 && n < max_entries) {
+      int* o = out7 + 7 * n;
+      o[0] = e.H; o[1] = e.W; o[2] = e.cin; o[3] = e.cout; o[4] = e.taps; o[5] = e.esize; o[6] = e.cfg;
+    }
+    ++n;
+  }
+  return n;
+}
+
+extern "C" int stv_conv_tune_import(const int* in7, int n_entries) {
+  if (n_entries < 0 || (n_entries > 0 && !in7)) return STV_ERR_ARG;
+  if (n_entries == 0) {                      // empty import: forget everything measured or imported so far
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    g_tune.clear();
+    return STV_OK;
+  }
+  for (int i = 0; i < n_entries; ++i) {
+    const int* e = in7 + 7 * i;
+    if (e[0] <= 0 || e[1] <= 0 || e[2] <= 0 || e[3] <= 0 || (e[5] != 2 && e[5] != 4) || !cfg_valid(e[6], e[3])) return STV_ERR_ARG;
+    if (e[4] != 9 && e[4] != 1 && e[4] != kRouteTaps) return STV_ERR_ARG;
+  }
+  std::lock_guard<std::mutex> lk(g_tune_mu);
+  for (int i = 0; i < n_entries; ++i) {
+    const int* e = in7 + 7 * i;
+    bool found = false;
+    for (TuneEntry& t : g_tune)
+      if (t.H == e[0] && t.W == e[1] && t.cin == e[2] && t.cout == e[3] && t.taps == e[4] && t.esize == e[5]) { t.cfg = e[6]; found = true; }
+    if (!found) g_tune.push_back(TuneEntry{e[0], e[1], e[2], e[3], e[4], e[5], e[6]});
+  }
+  return STV_OK;
+}
+
 extern "C" int stv_conv_tune(int H, int W, int cin, int cout, int taps, int dtype, void* stream) {
   if (H <= 0 || W <= 0 || cin <= 0 || cout <= 0 || (taps != 9 && taps != 1 && taps != kRouteTaps)) return -(100 + STV_ERR_ARG);
   if (dtype != STV_F32 && dtype != STV_BF16) return -(100 + STV_ERR_ARG);
@@ -1026,8 +1066,10 @@ extern "C" int stv_conv_tune(int H, int W, int cin, int cout, int taps, int dtyp
   if (taps == kRouteTaps && (size_t)4 * H * W * (size_t)cout * 2 >= (size_t)1 << 31) return -(100 + STV_ERR_ARG);
   const int esize = dtype == STV_BF16 ? 2 : 4;
   if ((cin % (32 / esize)) || (cout % (16 / esize))) return -1;          // direct-kernel shape: nothing to tune
-  if (const char* off = getenv("STV_CONV_TUNE"))
-    if (atoi(off) == 0) return choose_cfg(H, W, cin, cout, esize, taps);
+  // STV_CONV_TUNE: unset = use the table (imported + measured so far), never measure; 0 = analytic choice only;
+  // 1 = measure shapes the table does not know; 2 = the same behind a cache turn-over (cold operands)
+  const char* mode = getenv("STV_CONV_TUNE");
+  if (!mode || atoi(mode) <= 0) return choose_cfg(H, W, cin, cout, esize, taps);
   const int known = tuned_cfg(H, W, cin, cout, taps, esize);
   if (known >= 0) return known;
   hipStream_t st = static_cast<hipStream_t>(stream);
