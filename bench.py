@@ -266,7 +266,7 @@ def run_gpu(args, rank: int, world: int, device: torch.device, size: int, steps:
                     fl = conv_flops(meta) if meta[0] == OP["CONV"] else 0.0
                     f.write(f"{names.get(meta[0], meta[0]):18s} H{meta[1]:5d} W{meta[2]:5d} cin{meta[3]:4d} cout{meta[4]:4d} "
                             f"taps{meta[5]} n{meta[6]:9d}  {t * 1e3:9.1f} us  {fl / (t * 1e-3) / 1e12 if t > 0 else 0:8.1f} TF/s\n")
-        dom_name, dom = max(groups.items(), key=lambda kv: kv[1]["ms"])
+        dom_name, dom = max(((k, v) for k, v in groups.items() if v["flops"] > 0), key=lambda kv: kv[1]["ms"])
         peak = BF16_PEAK_TFLOPS if precision == "bf16" else FP32_PEAK_TFLOPS
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
         traffic, traffic_src = pmc_traffic(dom_name, size) if precision == "bf16" else (None, None)

@@ -189,6 +189,14 @@ extern "C" int stv_program_run(stv_program* prog, int use_graph, void* stream) {
     (void)hipGraphDestroy(prog->graph);
     prog->exec = nullptr;
     prog->graph = nullptr;
+    // the fork/join events and the side stream took part in the destroyed capture: start the new one with fresh ones
+    for (hipEvent_t e : prog->events) (void)hipEventDestroy(e);
+    prog->events.clear();
+    if (prog->side) {
+      (void)hipStreamSynchronize(prog->side);
+      (void)hipStreamDestroy(prog->side);
+      prog->side = nullptr;
+    }
   }
   if (!prog->exec) {
     // Eager warm-up first: one-time hipFuncSetAttribute calls must not land inside a capture.
