@@ -243,6 +243,14 @@ class HaloShard:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._host_p2p = dist.is_initialized() and dist.get_backend(group) == "gloo"
+        # Whole closure as ONE captured graph (the 27 program segments, the 26 halo exchanges and the Gram
+        # all-reduce in between): nothing is issued from Python while a step runs.  RCCL point-to-point and
+        # collectives are stream operations and capture like kernels; the gloo rehearsal stages rows through
+        # host memory and cannot.  STV_SPATIAL_GRAPH=0 keeps the eager segment-by-segment form.
+        import os  # noqa: PLC0415
+        self._graph_ok = os.environ.get("STV_SPATIAL_GRAPH", "1") != "0" and not self._host_p2p
+        self._graph: torch.cuda.CUDAGraph | None = None
+        self._graph_stream: torch.cuda.Stream | None = None
         dev = content_img.device
         _, _, H, W = content_img.shape
         self.H, self.W, self.dtype = H, W, dtype
@@ -379,6 +387,10 @@ class HaloShard:
         if down >= self.world:
             buf[-1].zero_()
 
+    def _peer(self, group_rank: int) -> int:
+        """Global rank of a rank of ``self.group``: isend / irecv / P2POp name their peers by GLOBAL rank."""
+        return group_rank if self.group is None else dist.get_global_rank(self.group, group_rank)
+
     def _p2p(self, send_top: torch.Tensor, send_bot: torch.Tensor, recv_top: torch.Tensor, recv_bot: torch.Tensor) -> None:
         up, down = self.rank - 1, self.rank + 1
         if self.world == 1:
@@ -389,11 +401,11 @@ class HaloShard:
             for peer, dst in ((up, recv_top), (down, recv_bot)):
                 if 0 <= peer < self.world:
                     h = torch.empty(dst.shape, dtype=dst.dtype).view(torch.uint8)
-                    reqs.append(dist.irecv(h, src=peer, group=self.group))
+                    reqs.append(dist.irecv(h, src=self._peer(peer), group=self.group))
                     back.append((dst, h))
             for peer, src in ((up, send_top), (down, send_bot)):
                 if 0 <= peer < self.world:
-                    reqs.append(dist.isend(src.detach().cpu().contiguous().view(torch.uint8), dst=peer, group=self.group))
+                    reqs.append(dist.isend(src.detach().cpu().contiguous().view(torch.uint8), dst=self._peer(peer), group=self.group))
             for r in reqs:
                 r.wait()
             for dst, h in back:
@@ -407,8 +419,8 @@ class HaloShard:
                 rbuf = dst if dst.is_contiguous() else torch.empty(dst.shape, dtype=dst.dtype, device=dst.device)
                 if rbuf is not dst:
                     back.append((dst, rbuf))
-                p2p.append(dist.P2POp(dist.irecv, rbuf.view(torch.uint8), peer, self.group))
-                p2p.append(dist.P2POp(dist.isend, src.detach().contiguous().view(torch.uint8), peer, self.group))
+                p2p.append(dist.P2POp(dist.irecv, rbuf.view(torch.uint8), self._peer(peer), self.group))
+                p2p.append(dist.P2POp(dist.isend, src.detach().contiguous().view(torch.uint8), self._peer(peer), self.group))
         for r in dist.batch_isend_irecv(p2p):
             r.wait()
         for dst, rbuf in back:
@@ -417,7 +429,35 @@ class HaloShard:
     # -- one evaluation -------------------------------------------------------------------------------
     def loss_and_grad(self) -> torch.Tensor:
         """Scores [style, content, total] of the whole image at the current ``x_core``; d(total)/dx of
-        this rank's rows lands in ``g_core``."""
+        this rank's rows lands in ``g_core``.  After a first eager evaluation (one-time kernel attributes,
+        allocations) the whole closure is captured once and replayed as one graph."""
+        if not self._graph_ok:
+            return self._closure_eager()
+        if self._graph is None:
+            out = self._closure_eager()                      # warm-up, and this call's result
+            try:
+                self._capture_closure()
+            except Exception as exc:  # noqa: BLE001 - a runtime that cannot capture a collective: stay eager
+                from .logging_utils import logger  # noqa: PLC0415
+                logger.warning("row-strip closure could not be captured as a graph (%s): running it segment by segment", exc)
+                self._graph_ok, self._graph = False, None
+            return out
+        self._graph.replay()
+        return self.scores[:3].clone()
+
+    def _capture_closure(self) -> None:
+        torch.cuda.synchronize(self.x_core.device)
+        self._graph_stream = torch.cuda.Stream(device=self.x_core.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=self._graph_stream):
+            self._closure_body()
+        self._graph = graph
+
+    def _closure_eager(self) -> torch.Tensor:
+        self._closure_body()
+        return self.scores[:3].clone()
+
+    def _closure_body(self) -> None:
         self.x_ext[:, :, 1:-1].copy_(self.x_core.detach())
         self._run(self._fwd)
         self.p1.run()
@@ -439,7 +479,6 @@ class HaloShard:
         self.p2.run()
         self._run(self._bwd)
         self.g_core.copy_(self.g_ext[:, :, 1:-1])
-        return self.scores[:3].clone()
 
     def set_image(self, x_full: torch.Tensor) -> None:
         with torch.no_grad():

@@ -131,28 +131,34 @@ def test_config_runs_at_full_length(size, steps, every, precision, monkeypatch):
     spread_max = 0.0
     for step, img in sorted(images.items()):
         s_ref, c_ref, t_ref = oracle_losses(img)
-        tol_k = ltol
         if bf16:
-            # What does bf16 storage do to ITSELF under a last-bit change of the image?  The rounding-faithful oracle
-            # re-evaluated at img * (1 + 1.2e-7 u): every fp32 sum lands a few ulps elsewhere, some bf16 roundings
-            # flip, and late in the run (losses small, the style score a squared difference of nearly equal Grams)
-            # that moves the losses by up to a percent.  Two correct evaluations cannot agree better than that
-            # spread; the HIP path must agree with the oracle within 4x of it (floor: the plain bf16 tolerance).
+            # What does bf16 storage do to ITSELF under a rounding-level change?  Every stored tensor of the HIP
+            # path is within one bf16 ulp of the oracle op on the same inputs (tests/test_gpu_bf16_layerwise.py), but
+            # which way a value rounds depends on the last bits of an fp32 sum: the first layer (split-bf16 matrix
+            # cores, sums good to 2^-16) already rounds 0.4 % of its outputs the other way, and nine layers on 70 % of
+            # the elements differ by an ulp (tests/diag/diag_bf16_late.py) - the content target included, so late in
+            # a run (|F - T| at rounding-noise level) the content score of two CORRECT evaluations differs by ~1 %.
+            # The yardstick is the rounding-faithful oracle against ITSELF with its input moved by 2^-16 relative:
+            # the HIP path must agree with it within 4x that spread (floor: the plain bf16 tolerance).
             g = torch.Generator().manual_seed(step)
-            pert = [oracle_losses(img * (1.0 + 1.2e-7 * (2.0 * torch.rand(img.shape, generator=g) - 1.0))) for _ in range(2)]
-            spread = max(abs(p[2] - t_ref) / abs(t_ref) for p in pert)
-            spread_max = max(spread_max, spread)
-            tol_k = max(ltol, 4.0 * spread)
+            pert = [oracle_losses(img * (1.0 + 2.0 ** -16 * (2.0 * torch.rand(img.shape, generator=g) - 1.0))) for _ in range(3)]
+            ref3 = (s_ref, c_ref, t_ref)
+            spread3 = [max(abs(p[i] - ref3[i]) / abs(ref3[i]) for p in pert) for i in range(3)]
+            spread_max = max(spread_max, max(spread3))
+            tol_k = [max(ltol, 4.0 * sp) for sp in spread3]
+        else:
+            tol_k = [ltol] * 3
         got = (history["style_loss"][step - 1], history["content_loss"][step - 1], history["total_loss"][step - 1])
         # each weighted term relative to itself - or, once the optimisation has made it a small part of the total
         # (the style score is a squared DIFFERENCE of nearly equal Grams by then, and bf16 rounding flips move it
         # by percents of itself), within `floor` of the total
         floor = (2e-3 if bf16 else 1e-6) * abs(t_ref)
-        for nm, wgt, a, b in (("style", oc.style_w, got[0], s_ref), ("content", oc.content_w, got[1], c_ref), ("total", 1.0, got[2], t_ref)):
+        for i, (nm, wgt, a, b) in enumerate((("style", oc.style_w, got[0], s_ref), ("content", oc.content_w, got[1], c_ref), ("total", 1.0, got[2], t_ref))):
             rel = abs(a - b) / abs(b)
             if wgt * abs(a - b) > floor:
                 worst = max(worst, rel)
-                assert rel <= tol_k, f"{case} step {step}: {nm} loss {a!r} vs oracle at the same image {b!r} (tolerance {tol_k:.1e})"
+                assert rel <= tol_k[i], (f"{case} step {step}: {nm} loss {a!r} vs oracle at the same image {b!r} "
+                                         f"(tolerance {tol_k[i]:.1e}; the oracle's own spreads here: {spread3 if bf16 else None})")
             elif nm == "total":
                 worst = max(worst, rel)
     record_parity(case, f"losses vs oracle at the same image, {len(images)} steps (rel)", worst, max(ltol, 4.0 * spread_max),

@@ -199,3 +199,120 @@ def test_halo_exchange_strips_equal_the_unsharded_result_adam_and_lbfgs(world):
     st = got[0]["lbfgs_state"]
     assert (st["n_iter"], st["hist_len"], st["skip"]) == (ref_state["n_iter"], ref_state["hist_len"], ref_state["skip"]) == (3, 2, 0)
     assert st["H_diag"] == pytest.approx(ref_state["H_diag"], rel=1e-3)
+
+
+# ------------------------------------------------------------------------------ closure as one captured graph
+def test_strip_closure_replayed_as_one_graph_equals_the_eager_segments(monkeypatch):
+    """HaloShard runs its closure - 27 program segments, the halo exchanges, the Gram all-reduce - as ONE
+    captured graph after the first (eager) evaluation (RCCL operations are stream operations and capture like
+    kernels; with a single strip the exchanges reduce to the zero-filled image border).  Replay vs
+    STV_SPATIAL_GRAPH=0, same inputs: bit-identical scores, gradient and images over three L-BFGS steps."""
+    from style_transfer_visualizer_amd import spatial
+    model, content, x0, dev = _setup()
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("STV_SPATIAL_GRAPH", mode)
+        shard = spatial.HaloShard(model._layers(), S_AT, C_AT, content, model.style_targets,
+                                  dtype=torch.float32, style_w=1e5, content_w=1.0)
+        shard.set_image(x0)
+        first = shard.loss_and_grad().clone()              # eager in both modes (graph mode: warm-up + capture)
+        second = shard.loss_and_grad().clone()             # graph mode: a replay
+        grad = shard.g_core.clone()
+        steps = [shard.step("lbfgs", lr=1.0).clone() for _ in range(3)]
+        assert (shard._graph is not None) == (mode == "1")
+        out[mode] = (first, second, grad, steps, shard.gather_image().clone())
+    for a, b in zip(out["0"][:3], out["1"][:3], strict=True):
+        assert torch.equal(a, b)
+    assert all(torch.equal(a, b) for a, b in zip(out["0"][3], out["1"][3], strict=True))
+    assert torch.equal(out["0"][4], out["1"][4])
+    # and the single strip IS the unsharded problem
+    x = x0.clone().requires_grad_(True)
+    s_ref, c_ref, t_ref = model.loss_and_grad(x, 1e5, 1.0)
+    assert torch.allclose(out["1"][0].cpu(), torch.stack((s_ref, c_ref, t_ref)).cpu(), rtol=2e-5, atol=0)
+
+
+def _subgroup_worker(rank: int, world: int, port: int, q) -> None:
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    group = dist.new_group(ranks=[1, 2])                  # every rank takes part in creating it
+    if rank == 0:
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    from style_transfer_visualizer_amd import spatial
+    model, content, x0, dev = _setup()
+    shard = spatial.HaloShard(model._layers(), S_AT, C_AT, content, model.style_targets, dtype=torch.float32,
+                              style_w=1e5, content_w=1.0, group=group)
+    shard.set_image(x0)
+    scores = shard.loss_and_grad()
+    torch.cuda.synchronize()
+    q.put((rank, (shard.rank, shard.c0, shard.c1, scores.cpu().numpy(), shard.g_core.cpu().numpy())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_halo_exchange_inside_a_subgroup_uses_global_peer_ranks():
+    """A 2-rank strip group that is NOT ranks 0..1 of the world (world = 3, group = {1, 2}): isend / irecv name
+    their peers by global rank, the strips by their rank in the group."""
+    model, content, x0, dev = _setup()
+    x = x0.clone().requires_grad_(True)
+    s_ref, c_ref, t_ref = model.loss_and_grad(x, 1e5, 1.0)
+    g_ref = x.grad.clone().cpu()
+    ref_scores = torch.stack((s_ref, c_ref, t_ref)).cpu()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_subgroup_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for world_rank, group_rank in ((1, 0), (2, 1)):
+        grank, c0, c1, scores, grad = got[world_rank]
+        assert (grank, c0, c1) == (group_rank, 256 * group_rank, 256 * (group_rank + 1))
+        assert torch.allclose(torch.from_numpy(scores), ref_scores, rtol=2e-5, atol=0)
+        err = float((torch.from_numpy(grad) - g_ref[:, :, c0:c1]).abs().max() / g_ref.abs().max())
+        assert err < 2e-5, f"world rank {world_rank}: own-rows gradient differs by {err:.2e}"
+
+
+# ------------------------------------------------------------------------------ a configs[4] strip in fp32
+def test_4k_strip_in_fp32_matches_the_oracle(monkeypatch):
+    """One strip of BASELINE configs[4] as a problem of its own: 544 rows x 3840 columns (the height
+    strip_rows gives each of 4 ranks at 2160 rows), full-width VGG19, fp32 parity mode - 535-MB activations,
+    3840-pixel rows, the strip schedule (halo rows, pooling over own rows) - against the CPU oracle on the same
+    image: losses to 1e-5, gradient to what ReLU / max-pool near-ties allow (tests/parity_util.py)."""
+    from oracle import core_model_ref as ocm
+    from style_transfer_visualizer_amd import core_model, spatial, synthetic
+    from tests.conftest import record_parity
+    monkeypatch.setenv("STV_SYNTHETIC_WEIGHTS", "0")
+    assert spatial.strip_rows(2160, 0, 4)[:2] == (0, 544)
+    dev = torch.device("cuda:0")
+    Hs, Ws = 544, 3840
+    S_L, C_L = [0, 5, 10, 19, 28], [21]
+    content = synthetic.synthetic_image(0, Hs, Ws)
+    style = synthetic.synthetic_image(1, 512, 512)
+    x0 = torch.randn(1, 3, Hs, Ws, generator=torch.Generator().manual_seed(0))
+    model = core_model.StyleContentModel(S_L, C_L, precision="fp32").to(dev)
+    targets = model._engine_for(style.to(dev)).capture_style(style.to(dev))
+    shard = spatial.HaloShard(model._layers(), S_L, C_L, content.to(dev), targets, dtype=torch.float32, style_w=1e5, content_w=1.0)
+    shard.set_image(x0.to(dev))
+    scores = shard.loss_and_grad().cpu()
+    g = shard.g_core.cpu()
+    weights = synthetic.synthetic_conv_weights(0)
+    oracle = ocm.OracleModel(ocm.vgg_program(weights, synthetic.VGG19_CFG), S_L, C_L)
+    oracle.set_targets(style, content)
+    s_ref, c_ref, t_ref, g_ref = ocm.loss_and_grad(oracle, x0, 1e5, 1.0)
+    case = "configs[4] strip 544x3840 fp32"
+    for nm, a, b in (("style", float(scores[0]), float(s_ref)), ("content", float(scores[1]), float(c_ref)), ("total", float(scores[2]), float(t_ref))):
+        rel = abs(a - b) / abs(b)
+        record_parity(case, f"{nm} loss vs oracle (rel)", rel, 1e-5)
+        assert rel <= 1e-5
+    rms = float((g - g_ref).norm() / g_ref.norm())
+    frac = float(((g - g_ref).abs() > 2e-4 * g_ref.abs().max()).float().mean())
+    record_parity(case, "gradient vs CPU-fp32 oracle (rel rms)", rms, 3e-3,
+                  f"{frac:.1e} of the pixels beyond 2e-4 of scale: receptive fields of ReLU / pool near-ties")
+    assert rms <= 3e-3 and frac <= 6e-2
+    del model, shard
+    torch.cuda.empty_cache()
