@@ -9,7 +9,7 @@ synthetic weights seed 0, content seed 0, style seed 1, ``init_method=random`` o
 weights.  What is asserted:
 
 * integer bookkeeping, bit-exact: step ids 1..N, one closure per step, history length, the logging steps;
-* every 50 (512^2) / 100 (1024^2) steps the CPU oracle - rounding to bf16 exactly where the kernels do - is
+* every 50 (512^2) / 250 (1024^2) steps the CPU oracle - rounding to bf16 exactly where the kernels do - is
   evaluated AT THE IMAGE THE HIP PATH HOLDS and must give the loss the HIP path logged for it (chaos-free:
   nothing is compared between two free-running trajectories);
 * the device L-BFGS state (``n_iter``, history length, skip / no-update flags) equals, at each of the first 110
@@ -52,14 +52,15 @@ class _Bar:
         return None
 
 
-@pytest.mark.parametrize("size,steps,every,precision", [(512, 300, 50, "bf16"), (512, 300, 50, "fp32"), (1024, 500, 100, "bf16")])
+@pytest.mark.parametrize("size,steps,every,precision", [(512, 300, 50, "bf16"), (512, 300, 50, "fp32"), (1024, 500, 250, "bf16")])
 def test_config_runs_at_full_length(size, steps, every, precision, monkeypatch):
     monkeypatch.setenv("STV_SYNTHETIC_WEIGHTS", "0")
     bf16 = precision == "bf16"
     # losses vs the oracle at the same image.  fp32 (parity mode, the reference's arithmetic): rounding level.
-    # bf16: the oracle rounds where the kernels round, but fp32 sums in another order flip ~1e-3 of those
-    # roundings (tests/test_gpu_bf16_layerwise.py bounds every stored tensor to one ulp); a bf16 ulp is 4e-3.
-    ltol = 5e-3 if bf16 else 1e-4
+    # bf16: the oracle rounds where the kernels round (and is given the model's targets, see below); fp32 sums
+    # in another order still flip roundings layer by layer (tests/test_gpu_bf16_layerwise.py bounds every stored
+    # tensor to one ulp), which moves the losses by ~1e-4: same 2e-3 as tests/test_gpu_fullsize.py.
+    ltol = 2e-3 if bf16 else 1e-4
     case = f"configs[{1 if size == 512 else 2}] {size}x{size} x{steps} {precision}"
     cfg = stv_config.StyleTransferConfig.model_validate({})
     oc = cfg.optimization
@@ -121,6 +122,16 @@ def test_config_runs_at_full_length(size, steps, every, precision, monkeypatch):
     oracle = ocm.OracleModel(ocm.vgg_program(weights, synthetic.VGG19_CFG), S_LAYERS, C_LAYERS, bf16_storage=bf16,
                              fused_style_taps=fused if bf16 else None)
     oracle.set_targets(style, content)
+    if bf16:
+        # In bf16 the TARGETS are rounded tensors too, and which way each element rounded is part of the problem
+        # the run solved: 70 % of the content target's elements differ by an ulp between two correct bf16
+        # evaluations (tests/diag/diag_bf16_late.py), and after 100+ steps the image has been fitted to the HIP
+        # path's realisation of that rounding - against another realisation its content score is ~0.7 % higher,
+        # for the HIP features and the oracle's alike.  "Oracle at the same image" therefore means: same image,
+        # same targets (the model's public ``content_targets`` / ``style_targets``, reference core_model.py:218-232);
+        # that the targets themselves are right is the business of tests/test_gpu_fullsize.py.
+        oracle.content_targets = [t.float().cpu().contiguous() for t in model.content_targets]
+        oracle.style_targets = [t.float().cpu() for t in model.style_targets]
     t1 = time.time()
     worst = 0.0
     def oracle_losses(img):
@@ -128,27 +139,10 @@ def test_config_runs_at_full_length(size, steps, every, precision, monkeypatch):
             s_l, c_l = oracle(img)
         s_v, c_v = float(torch.stack(s_l).sum()), float(torch.stack(c_l).sum())
         return s_v, c_v, oc.style_w * s_v + oc.content_w * c_v
-    spread_max = 0.0
     for step, img in sorted(images.items()):
         s_ref, c_ref, t_ref = oracle_losses(img)
-        if bf16:
-            # What does bf16 storage do to ITSELF under a rounding-level change?  Every stored tensor of the HIP
-            # path is within one bf16 ulp of the oracle op on the same inputs (tests/test_gpu_bf16_layerwise.py), but
-            # which way a value rounds depends on the last bits of an fp32 sum: the first layer (split-bf16 matrix
-            # cores, sums good to 2^-16) already rounds 0.4 % of its outputs the other way, and nine layers on 70 % of
-            # the elements differ by an ulp (tests/diag/diag_bf16_late.py) - the content target included, so late in
-            # a run (|F - T| at rounding-noise level) the content score of two CORRECT evaluations differs by ~1 %.
-            # The yardstick is the rounding-faithful oracle against ITSELF with its input moved by 2^-16 relative:
-            # the HIP path must agree with it within 4x that spread (floor: the plain bf16 tolerance).
-            g = torch.Generator().manual_seed(step)
-            pert = [oracle_losses(img * (1.0 + 2.0 ** -16 * (2.0 * torch.rand(img.shape, generator=g) - 1.0))) for _ in range(3)]
-            ref3 = (s_ref, c_ref, t_ref)
-            spread3 = [max(abs(p[i] - ref3[i]) / abs(ref3[i]) for p in pert) for i in range(3)]
-            spread_max = max(spread_max, max(spread3))
-            tol_k = [max(ltol, 4.0 * sp) for sp in spread3]
-        else:
-            tol_k = [ltol] * 3
         got = (history["style_loss"][step - 1], history["content_loss"][step - 1], history["total_loss"][step - 1])
+        tol_k = [ltol] * 3
         # each weighted term relative to itself - or, once the optimisation has made it a small part of the total
         # (the style score is a squared DIFFERENCE of nearly equal Grams by then, and bf16 rounding flips move it
         # by percents of itself), within `floor` of the total
@@ -157,12 +151,11 @@ def test_config_runs_at_full_length(size, steps, every, precision, monkeypatch):
             rel = abs(a - b) / abs(b)
             if wgt * abs(a - b) > floor:
                 worst = max(worst, rel)
-                assert rel <= tol_k[i], (f"{case} step {step}: {nm} loss {a!r} vs oracle at the same image {b!r} "
-                                         f"(tolerance {tol_k[i]:.1e}; the oracle's own spreads here: {spread3 if bf16 else None})")
+                assert rel <= tol_k[i], f"{case} step {step}: {nm} loss {a!r} vs oracle at the same image {b!r} (tolerance {tol_k[i]:.1e})"
             elif nm == "total":
                 worst = max(worst, rel)
-    record_parity(case, f"losses vs oracle at the same image, {len(images)} steps (rel)", worst, max(ltol, 4.0 * spread_max),
-                  (f"bf16 oracle's own spread under a last-bit change of the image: {spread_max:.1e}; " if bf16 else "") +
+    record_parity(case, f"losses vs oracle at the same image, {len(images)} steps (rel)", worst, ltol,
+                  ("oracle given the model's (bf16) targets; " if bf16 else "") +
                   f"steps {sorted(images)}; loss {totals[0]:.3e} -> {totals[-1]:.3e}; {steps / wall:.0f} steps/s incl. test "
                   f"callbacks; oracle {time.time() - t1:.0f} s")
 

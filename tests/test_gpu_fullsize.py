@@ -213,7 +213,7 @@ def test_fullsize_closure_and_lbfgs_steps_match_oracle(size, precision, monkeypa
             xc = x.detach().cpu()
             ref_k = ocm.loss_and_grad(oracle, xc, STYLE_W, CONTENT_W)
             check(f"step{step + 1}", losses, g, ref_k, g64_at(xc))
-            if not bf16 and step == 3:
+            if not bf16 and step == 3 and size <= 512:       # (1024^2: the same-branch check at step 1 only - 70 s of float64 each)
                 check_same_branch(f"step{step + 1}", g, ref_k[3], xc, pu.hip_decisions(model))
     print(f"{case}: oracle time {time.time() - t0:.0f} s")
     del model, x
