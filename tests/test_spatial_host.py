@@ -33,7 +33,11 @@ def test_p2p_rccl_branch_stages_non_contiguous_rows(monkeypatch):
         return [Done() for _ in ops]
     monkeypatch.setattr(dist, "P2POp", FakeOp)
     monkeypatch.setattr(dist, "batch_isend_irecv", fake_batch)
-    shard = types.SimpleNamespace(rank=1, world=3, group=None, _host_p2p=False)       # a middle rank: two neighbours
+    def make(rank, group=None):
+        ns = types.SimpleNamespace(rank=rank, world=3, group=group, _host_p2p=False)
+        ns._peer = types.MethodType(spatial.HaloShard._peer, ns)
+        return ns
+    shard = make(1)       # a middle rank: two neighbours
     # NCHW image rows (non-contiguous [1, 3, W] slices) and NHWC activation rows (contiguous [W, C], bf16)
     x = torch.arange(1 * 3 * 6 * 5, dtype=torch.float32).reshape(1, 3, 6, 5)
     want_top, want_bot = x[:, :, 1].clone(), x[:, :, 4].clone()
@@ -44,8 +48,14 @@ def test_p2p_rccl_branch_stages_non_contiguous_rows(monkeypatch):
     spatial.HaloShard._p2p(shard, a[1], a[4], a[0], a[5])
     assert torch.equal(a[0], want_top) and torch.equal(a[5], want_bot)
     # an edge rank only talks to its one neighbour
-    edge = types.SimpleNamespace(rank=0, world=3, group=None, _host_p2p=False)
+    edge = make(0)
     sent.clear()
     top_before = a[0].clone()
     spatial.HaloShard._p2p(edge, a[1], a[4], a[0], a[5])
     assert set(sent) == {1} and torch.equal(a[0], top_before)
+    # inside a sub-group the peers are named by GLOBAL rank (group ranks 0, 1, 2 = world ranks 4, 5, 7)
+    monkeypatch.setattr(dist, "get_global_rank", lambda group, r: group[r])
+    sent.clear()
+    sub = make(1, group=[4, 5, 7])
+    spatial.HaloShard._p2p(sub, a[1], a[4], a[0], a[5])
+    assert set(sent) == {4, 7}
