@@ -658,6 +658,7 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
     };
     auto full_off = [&](int mt) -> uint32_t {
       const int gy = y0 + wm * C::MT + mt, gx = x0 + r;
+      if (STV_DIAG & 2) return kOob;                   // (timing knock-out: no output stores)
       return (gy < a.H && gx < a.W) ? (uint32_t)(((gy * a.W + gx) * a.cout) * (int)sizeof(T)) : kOob;
     };
     emit([&](int mt, int nt, int i) { return acc[mt][nt][i]; }, full_off, rs_y, C::MT, do_mask, do_acc);
