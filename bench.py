@@ -249,6 +249,11 @@ def run_gpu(args, rank: int, world: int, device: torch.device, size: int, steps:
         # per op the MEDIAN of the passes: one disturbed pass (a clock dip, a neighbour's tail) must not rate a kernel
         ms = [sorted(p[i] for p in passes)[len(passes) // 2] for i in range(prog.n_ops)]
         ms_hot = [sorted(p[i] for p in hot)[len(hot) // 2] for i in range(prog.n_ops)]
+        # An event pair around a single launch costs a few microseconds of its own.  Calibrated against the replayed
+        # graph: the ops' true durations add up to the closure time minus the ~0.6 us between consecutive graph
+        # kernels (tools/gap_report.py), so the per-op excess of the event-timed sum over that is the event cost.
+        event_cost = max(0.0, (sum(ms) - (closure_ms - 0.0006 * prog.n_ops)) / prog.n_ops)
+        ms = [max(t - event_cost, 0.25 * t) for t in ms]
         groups: dict = {}
         for meta, fl, t, th in zip(prog.op_meta, prog.op_flags, ms, ms_hot, strict=True):
             g = kernel_group(meta, OP, 1 if precision == "bf16" else 0, fl)
@@ -276,7 +281,9 @@ def run_gpu(args, rank: int, world: int, device: torch.device, size: int, steps:
             "launches_per_step": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 5),
             "avg_launch_ms_cache_hot": round(dom["ms_hot"] / dom["launches"], 5),
             "flop_per_launch": dom["flops"] / dom["launches"],
-            "timing": "HIP events around each op of the step program, in program order (operands as the step leaves them)",
+            "timing": ("HIP events around each op of the step program, in program order (operands as the step leaves them), "
+                       f"minus the event pair's own cost ({event_cost * 1e3:.1f} us per op, calibrated so that the ops add up to "
+                       "the replayed closure)"),
         }
         # forward + Gram/content losses = every op up to the score combine (SURVEY.md §8(d) byte model)
         # (timed in context above: replays of the forward-only program; the per-op pass below runs
