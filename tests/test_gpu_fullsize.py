@@ -161,13 +161,17 @@ def test_fullsize_closure_and_lbfgs_steps_match_oracle(size, precision, monkeypa
             rel = abs(got - want) / abs(want)
             record_parity(case, f"{tag} {nm} loss (rel)", rel, ltol)
             assert rel <= ltol, f"{case} {tag}: {nm} loss {got!r} vs oracle {want!r}"
-        if not bf16:
+        if not bf16 and g64 is not None:
             err_hip = float((g.double() - g64).norm() / g64.norm())
             err_cpu = float((g_ref.double() - g64).norm() / g64.norm())
             mx, rms, _ = _grad_stats(g, g_ref, 2e-4)
             record_parity(case, f"{tag} grad vs fp64 (rel rms)", err_hip, max(4 * err_cpu, GRAD_FLOOR),
                           f"decision near-ties included; reference's CPU-fp32 path vs fp64: {err_cpu:.2e}; HIP vs CPU-fp32 directly: rms {rms:.1e} max {mx:.1e} of scale")
             assert err_hip <= max(4 * err_cpu, GRAD_FLOOR), f"{case} {tag}: HIP {err_hip:.2e} vs fp64, CPU-fp32 {err_cpu:.2e}"
+        elif not bf16:          # no float64 evaluation at this step: the two fp32 paths against each other (near-ties included)
+            rel = float((g - g_ref).norm() / g_ref.norm())
+            record_parity(case, f"{tag} grad HIP vs CPU-fp32 (rel rms)", rel, GRAD_FLOOR, "decision near-ties included")
+            assert rel <= GRAD_FLOOR
         else:
             rel = float((g - g_ref).norm() / g_ref.norm())
             record_parity(case, f"{tag} grad rms (of rms)", rel, grms_tol, "sanity bound only: rounding chaos, see test_gpu_bf16_layerwise.py")
@@ -212,7 +216,8 @@ def test_fullsize_closure_and_lbfgs_steps_match_oracle(size, precision, monkeypa
         if size <= 512 or step == 3:
             xc = x.detach().cpu()
             ref_k = ocm.loss_and_grad(oracle, xc, STYLE_W, CONTENT_W)
-            check(f"step{step + 1}", losses, g, ref_k, g64_at(xc))
+            # (1024^2: the float64 evaluation - 20 s - at step 1 only; losses against the fp32 oracle here)
+            check(f"step{step + 1}", losses, g, ref_k, g64_at(xc) if size <= 512 else None)
             if not bf16 and step == 3 and size <= 512:       # (1024^2: the same-branch check at step 1 only - 70 s of float64 each)
                 check_same_branch(f"step{step + 1}", g, ref_k[3], xc, pu.hip_decisions(model))
     print(f"{case}: oracle time {time.time() - t0:.0f} s")

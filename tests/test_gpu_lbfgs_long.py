@@ -96,7 +96,11 @@ def _run(case: str, n: int, history: int, compact: bool, shards: tuple[int, ...]
     grad = _objective(n)
     dev = _Device(n, history, compact, shards)
     x32 = torch.zeros(n)
-    x64 = torch.zeros(n, dtype=torch.float64)
+    # the float64 yardstick runs torch's own vector ops on the GPU for large n (same algorithm, same arithmetic
+    # width; on the host cores it was 50 of this test's 80 s at n = 3 x 512^2); the fp32 twin - the reference's
+    # arithmetic, bit-identical to torch.optim.LBFGS on CPU - stays on the CPU
+    dev64 = DEV if n >= 500_000 else torch.device("cpu")
+    x64 = torch.zeros(n, dtype=torch.float64, device=dev64)
     twin32 = optim_ref.LbfgsRef(x32, lr=1.0, history_size=history)
     twin64 = optim_ref.LbfgsRef(x64, lr=1.0, history_size=history)
     steps = history + extra_steps
@@ -117,10 +121,11 @@ def _run(case: str, n: int, history: int, compact: bool, shards: tuple[int, ...]
         else:
             g = grad(x_before)
         b32, b64 = x32.clone(), x64.clone()
+        g64 = g.to(dev64).double()
         len_before = len(twin32.old_dirs)
         newest = twin32.old_dirs[-1] if twin32.old_dirs else None
         twin32.step(lambda: (zero, g.clone()))
-        twin64.step(lambda: (zero.double(), g.double()))
+        twin64.step(lambda: (zero.double(), g64))
         dev.step(g)
         x_after = dev.image()
         assert torch.isfinite(x_after).all(), f"{case}: non-finite image at step {step}"
@@ -139,7 +144,7 @@ def _run(case: str, n: int, history: int, compact: bool, shards: tuple[int, ...]
         # ---- the update each optimizer applied ----------------------------------------------------------
         u_dev = (x_after.double() - x_before.double())
         u_32 = (x32 - b32).double()
-        u_64 = x64 - b64
+        u_64 = (x64 - b64).cpu()
         scale = float(u_64.abs().max())
         if step in (ev_tiny, ev_flat):
             assert scale == 0.0 and float(u_dev.abs().max()) == 0.0 and float(u_32.abs().max()) == 0.0, \
@@ -162,6 +167,7 @@ def _run(case: str, n: int, history: int, compact: bool, shards: tuple[int, ...]
     if compact:   # ring of history+1 slots: the head has advanced once per eviction
         assert st["head"] == pushes_after_full % (history + 1), f"{case}: head {st['head']} after {pushes_after_full} evictions"
     x_end = dev.image().double()
+    x64 = x64.cpu()
     dx = float((x_end - x64).abs().max() / x64.abs().max())
     dx32 = float((x32.double() - x64).abs().max() / x64.abs().max())
     note = (f"fp32 reference's own worst {worst_32:.1e}; worst device/reference ratio {worst_ratio:.2f}; {steps} steps, "
