@@ -158,9 +158,15 @@ def test_trajectory_matches_reference(golden_case: GoldenCase, monkeypatch):
         images = [("x_final per pixel (of range)", out.detach().cpu(), case.arrays["x_final"],
                    float(case.arrays["x_final_sensitivity"]))]
 
-    def check(ref_hist: dict, ref_images: list, what: str) -> list[str]:
-        """Compare losses and images with one reference run; returns the failures (empty: all within tolerance)."""
+    def check(ref_hist: dict, ref_images: list, what: str) -> tuple[list[str], list[tuple]]:
+        """Compare losses and images with one reference run; returns the failures (empty: all within tolerance)
+        and the parity-table rows (recorded by the caller: a plain comparison that a decision flip explains is
+        reported, not asserted)."""
         bad = []
+        rows: list[tuple] = []
+
+        def record_parity(*row):                         # (shadows the module-level function inside check)
+            rows.append(row)
         ref_total = np.asarray(ref_hist["total_loss"])
         first = min(2, steps)
         dev_first = float(np.abs(np.asarray(history["total_loss"][:first]) / ref_total[:first] - 1.0).max())
@@ -193,11 +199,14 @@ def test_trajectory_matches_reference(golden_case: GoldenCase, monkeypatch):
                 bad.append(f"{tag}: {dev:.2e} > {tol:.2e}")
         if compared == 0:
             bad.append("no image of this fixture could be compared")
-        return bad
+        return bad, rows
 
     golden_hist = {k: case.arrays[k] for k in ("total_loss", "style_loss", "content_loss")}
-    bad = check(golden_hist, [ref for _, _, ref, _ in images], "")
+    from tests.conftest import record_parity as emit
+    bad, rows = check(golden_hist, [ref for _, _, ref, _ in images], "")
     if not bad:
+        for row in rows:
+            emit(*row)
         return
     # ---- Not within tolerance of the stored trajectory.  The one legitimate cause is a ReLU / max-pool near-tie
     # that the two fp32 evaluations decide differently (tests/parity_util.py) - from there on the trajectories
@@ -242,7 +251,17 @@ def test_trajectory_matches_reference(golden_case: GoldenCase, monkeypatch):
     rep_images = [xs.numpy() for xs in replay["x_steps"]] if "x_steps" in case.arrays else [replay["x"].numpy()]
     note = (f" [reference replayed on the HIP path's branch: at step {step_f} {flips} ReLU/pool decision(s) differ, "
             f"float64 gap <= {gap:.1e} of the layer rms]")
-    bad2 = check(rep_hist, rep_images, note)
+    for row in rows:      # the plain comparison: reported (tolerance NaN), the replay rows below are the assertion
+        case_, qty, dev_, tol_, *rest = row
+        if tol_ != tol_:                                 # already a reported-only row
+            emit(*row)
+            continue
+        over = not dev_ <= tol_
+        emit(case_, qty, dev_, float("nan") if over else tol_,
+             (f"reported only - beyond {tol_:.1e} across the decision flip at step {step_f}: see the replayed rows" if over else (rest[0] if rest else "")))
+    bad2, rows2 = check(rep_hist, rep_images, note)
+    for row in rows2:
+        emit(*row)
     assert not bad2, f"{name}: differs from the reference even on its own branch: {bad2} (plain comparison: {bad})"
 
 
