@@ -422,6 +422,14 @@ def host_cpu() -> dict:
     return {"model": model, "logical": logical, "physical": physical, "allowed": allowed, "threads": threads}
 
 
+def _rccl_version() -> str:
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(str(p) for p in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception:  # noqa: BLE001 - a version string must never take the bench line down
+        return "unknown"
+
+
 def _tile_info() -> dict:
     from style_transfer_visualizer_amd import _lib
     info = dict(_lib.tile_table_info)
@@ -547,7 +555,7 @@ def main() -> None:
                 "lbfgs_history_prefill_steps": info.get("prefill", 0),
                 "timed_region": "exactly --steps optimizer steps at a full L-BFGS history (m = 100), after --warmup untimed ones",
                 "world_size": world,
-                "collectives": (f"RCCL {'.'.join(str(v) for v in torch.cuda.nccl.version())} (torch.distributed backend "
+                "collectives": (f"RCCL {_rccl_version()} (torch.distributed backend "
                                 f"'{args.dist_backend}'): one all-gather of the final images after the timed region") if world > 1 else None,
             },
             "tiles": _tile_info(),
