@@ -539,3 +539,37 @@ def test_4k_image_runs(monkeypatch):
     assert torch.isfinite(x).all()
     del model, x, adam
     torch.cuda.empty_cache()
+
+
+def test_4k_whole_image_in_fp32_matches_the_oracle(monkeypatch):
+    """BASELINE configs[4]'s image (3840x2160) as ONE piece on one GPU in fp32 parity mode: its 64-channel
+    activations are 1.98 GiB - just inside the 32-bit buffer offsets of conv_igemm - so this exercises byte
+    offsets up to 2^31 in every kernel of the path.  Against the CPU oracle on the same image (26 s on the host
+    cores): losses to 1e-5, gradient to what ReLU / max-pool near-ties allow at 5e8 activations."""
+    monkeypatch.setenv("STV_SYNTHETIC_WEIGHTS", "0")
+    H, W = 2160, 3840
+    S_L, C_L = [0, 5, 10, 19, 28], [21]
+    content = synthetic.synthetic_image(0, H, W)
+    style = synthetic.synthetic_image(1, 512, 512)
+    x0 = torch.randn(1, 3, H, W, generator=torch.Generator().manual_seed(0))
+    model = core_model.StyleContentModel(S_L, C_L, precision="fp32").to(DEV)
+    model.set_targets(style.to(DEV), content.to(DEV))
+    x = x0.to(DEV).requires_grad_(True)
+    s, c, t = model.loss_and_grad(x, 1e5, 1.0)
+    got = (float(s), float(c), float(t))
+    g = x.grad.detach().cpu()
+    del model, x
+    torch.cuda.empty_cache()
+    oracle = ocm.OracleModel(ocm.vgg_program(synthetic.synthetic_conv_weights(0), synthetic.VGG19_CFG), S_L, C_L)
+    oracle.set_targets(style, content)
+    s_ref, c_ref, t_ref, g_ref = ocm.loss_and_grad(oracle, x0, 1e5, 1.0)
+    case = "configs[4] whole image 3840x2160 fp32"
+    for nm, a, b in (("style", got[0], float(s_ref)), ("content", got[1], float(c_ref)), ("total", got[2], float(t_ref))):
+        rel = abs(a - b) / abs(b)
+        record_parity(case, f"{nm} loss vs oracle (rel)", rel, 1e-5)
+        assert rel <= 1e-5, f"{nm}: {a!r} vs {b!r}"
+    rms = float((g - g_ref).norm() / g_ref.norm())
+    # bottom rows separately: the largest byte offsets
+    tail = float((g[:, :, -64:] - g_ref[:, :, -64:]).norm() / g_ref[:, :, -64:].norm())
+    record_parity(case, "gradient vs CPU-fp32 oracle (rel rms)", rms, 4e-3, f"last 64 rows alone: {tail:.1e}; ReLU / pool near-ties included")
+    assert rms <= 4e-3 and tail <= 8e-3
