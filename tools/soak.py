@@ -1,5 +1,5 @@
 import os, sys, time, math
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("STV_SYNTHETIC_WEIGHTS", "0")
 import torch
 from style_transfer_visualizer_amd import config as stv_config, core_model, optimization, synthetic
@@ -20,4 +20,9 @@ t0 = time.time()
 out, hist, _ = optimization.OptimizationRunner(model, x, cfg, optimizer=opt, progress_bar=Bar()).run()
 torch.cuda.synchronize()
 tl = hist["total_loss"]
+st = opt.device_state()
+print(f"optimizer state at the end: {st}")
+print("every 250th logged total loss:", " ".join(f"{v:.4e}" for v in tl[::250]))
+nondecr = sum(1 for a, b in zip(tl[:-1], tl[1:]) if b > a)
+print(f"steps whose loss went up: {nondecr} of {len(tl) - 1} (L-BFGS without line search is not monotone)")
 print(f"{size}^2 {steps} steps in {time.time()-t0:.1f}s; loss first {tl[0]:.4e} min {min(tl):.4e} last {tl[-1]:.4e}; finite {all(math.isfinite(v) for v in tl)}; image finite {bool(torch.isfinite(out).all())} range [{float(out.min()):.2f},{float(out.max()):.2f}]")
