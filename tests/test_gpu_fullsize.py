@@ -268,3 +268,52 @@ def test_gram_chain_at_full_pixel_counts(n_pixels, C, precision):
     stol = 1e-5 if precision == "fp32" else 2.0 ** -8
     record_parity(case, "seed S (of max)", float(sdev.max()), stol)
     assert float(sdev.max()) <= stol
+
+
+@pytest.mark.parametrize("size", [512, 1024])
+def test_gradient_is_the_derivative_of_the_loss_at_full_size(size, monkeypatch):
+    """A property that needs no oracle: the gradient the backward kernels write must be the derivative of the loss
+    the forward kernels compute.  Central differences of the fp32 loss along three directions v (step chosen so
+    that the loss moves by ~1e-3 of itself: truncation error ~1e-6, rounding noise of the two fp32 losses ~1e-4
+    of the difference) against g.v, at the sizes of BASELINE configs[1] / configs[2]; three directions, one of
+    them confined to the image border (the zero-padding rows and columns of every layer)."""
+    monkeypatch.setenv("STV_SYNTHETIC_WEIGHTS", "0")
+    case = f"vgg19_{size}x{size}_fp32 derivative"
+    content = synthetic.synthetic_image(0, size, size).to(DEV)
+    style = synthetic.synthetic_image(1, size, size).to(DEV)
+    model = core_model.StyleContentModel(S_LAYERS, C_LAYERS, precision="fp32").to(DEV)
+    model.set_targets(style, content)
+    x = torch.randn(1, 3, size, size, generator=torch.Generator().manual_seed(3)).to(DEV).requires_grad_(True)
+    _, _, t0 = model.loss_and_grad(x, STYLE_W, CONTENT_W)
+    f0 = float(t0)
+    g = x.grad.detach().clone().double()
+    gen = torch.Generator().manual_seed(11)
+    for k in range(3):
+        # directions with a sizeable component along the gradient (a random direction in 3e6 dimensions has
+        # g.v ~ |g| / 1,700: the step that moves the loss by 1e-3 would leave the linear regime): the gradient
+        # itself, the gradient plus an equally long random vector, and the gradient on the border pixels only
+        r = torch.randn(x.shape, generator=gen).to(DEV).double()
+        v = g / g.norm()
+        if k == 1:
+            v = v + r / r.norm()
+        if k == 2:
+            mask = torch.zeros_like(v)
+            mask[..., :2, :] = 1; mask[..., -2:, :] = 1; mask[..., :, :2] = 1; mask[..., :, -2:] = 1
+            v = v * mask
+        v = v / v.norm()
+        gv = float((g * v).sum())
+        # loss moves by ~1e-3 of itself (border direction: 2e-4 - the same loss change concentrated on 0.4 % of
+        # the pixels would push each of them across many ReLU kinks; its tolerance allows for the fp32 loss noise)
+        move, tol = (1e-3, 2e-3) if k < 2 else (2e-4, 1.5e-2)
+        eps = move * abs(f0) / max(abs(gv), 1e-30)
+        fs = []
+        for sgn in (1.0, -1.0):
+            xp = (x.detach().double() + sgn * eps * v).float().requires_grad_(True)
+            fs.append(float(model.loss_and_grad(xp, STYLE_W, CONTENT_W)[2]))
+        fd = (fs[0] - fs[1]) / (2 * eps)
+        rel = abs(fd - gv) / abs(gv)
+        record_parity(case, f"central difference vs g.v, direction {k} (rel)", rel, tol,
+                      ("along the gradient", "gradient + random", "gradient on the border pixels only")[k])
+        assert rel <= tol, f"{case} direction {k}: finite difference {fd!r} vs g.v {gv!r}"
+    del model, x
+    torch.cuda.empty_cache()
