@@ -47,3 +47,30 @@ def test_bad_arguments_are_rejected_not_executed():
     assert lib.stv_conv_igemm(None, None, None, None, None, 8, 8, 16, 16, 9, 0, 0, None) == 1
     assert lib.stv_gram_partial(None, None, 10, 64, 0, None) == 1
     assert lib.stv_lbfgs_step(None, None, None, None, 10, 100, 0, 1.0, 1e-7, 1e-9, None) == 1
+
+
+def test_tile_table_round_trip_and_modes(monkeypatch):
+    """The persisted tile choices reach the library at load time (host-only calls, no GPU): export returns what
+    conv_tiles_gfx950.json holds; a shape's tile is the table's unless STV_CONV_TUNE=0 asks for the analytic one;
+    malformed entries are rejected, an empty import clears the table."""
+    import json
+
+    lib = _lib.load()
+    doc = json.load(open(_lib.TILE_TABLE_PATH))
+    entries = _lib.export_tile_table()
+    want = {(e["H"], e["W"], e["cin"], e["cout"], e["taps"], e["elem_bytes"]): e["cfg"] for e in doc["entries"]}
+    got = {(e["H"], e["W"], e["cin"], e["cout"], e["taps"], e["elem_bytes"]): e["cfg"] for e in entries}
+    assert want and all(got.get(k) == v for k, v in want.items())
+    differing = [e for e in doc["entries"] if e["cfg"] != e["analytic"] and e["taps"] == 9 and e["elem_bytes"] == 2]
+    assert differing, "the measured table should differ from the analytic choice somewhere"
+    e = differing[0]
+    monkeypatch.delenv("STV_CONV_TUNE", raising=False)
+    assert lib.stv_conv_config(e["H"], e["W"], e["cin"], e["cout"], 9, _lib.STV_BF16) == e["cfg"]
+    monkeypatch.setenv("STV_CONV_TUNE", "0")
+    assert lib.stv_conv_config(e["H"], e["W"], e["cin"], e["cout"], 9, _lib.STV_BF16) == e["analytic"]
+    bad = (ctypes.c_int * 7)(64, 64, 512, 512, 9, 3, 4)          # element size 3
+    assert lib.stv_conv_tune_import(bad, 1) == 1
+    n_before = lib.stv_conv_tune_export(None, 0)
+    assert lib.stv_conv_tune_import(None, 0) == 0 and lib.stv_conv_tune_export(None, 0) == 0
+    _lib._import_tile_table(lib)                                  # restore for the tests that follow
+    assert lib.stv_conv_tune_export(None, 0) == n_before

@@ -167,3 +167,32 @@ def test_config_runs_at_full_length(size, steps, every, precision, monkeypatch):
                 fh.write(f"{k + 1},{history['style_loss'][k]!r},{history['content_loss'][k]!r},{history['total_loss'][k]!r}\n")
     del model, x, opt, runner
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_a_run_is_bit_reproducible(precision, monkeypatch):
+    """Same seed, same inputs, two fresh models: the image after 120 L-BFGS steps (history full, ring wrapped) and
+    every logged loss must be BIT-identical.  Nothing on the path sums in a timing-dependent order: split-K slabs
+    and per-wave partial sums are reduced in fixed order, no float atomics, and the tile of every conv shape comes
+    from the persisted table (style_transfer_visualizer_amd/conv_tiles_gfx950.json), not from a measurement."""
+    monkeypatch.setenv("STV_SYNTHETIC_WEIGHTS", "0")
+    monkeypatch.delenv("STV_CONV_TUNE", raising=False)          # the product's default: tiles from the table
+    size, steps = 512, 120
+    outs = []
+    for _ in range(2):
+        cfg = stv_config.StyleTransferConfig.model_validate({})
+        oc = cfg.optimization
+        oc.steps, oc.init_method = steps, "random"
+        cfg.hardware.precision = precision
+        cfg.video.create_video = False
+        torch.manual_seed(0)
+        content = synthetic.synthetic_image(0, size, size).to(DEV)
+        style = synthetic.synthetic_image(1, size, size).to(DEV)
+        model, x, opt = core_model.prepare_model_and_input(content, style, DEV, oc, precision=precision)
+        out, hist, _ = optimization.OptimizationRunner(model, x, cfg, optimizer=opt, progress_bar=_Bar()).run()
+        outs.append((out.detach().cpu().clone(), hist["total_loss"], opt.device_state()))
+        del model, x, opt
+        torch.cuda.empty_cache()
+    assert torch.equal(outs[0][0], outs[1][0]), "final images differ between two identical runs"
+    assert outs[0][1] == outs[1][1], "loss histories differ between two identical runs"
+    assert outs[0][2] == outs[1][2]
