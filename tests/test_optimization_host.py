@@ -263,3 +263,34 @@ def test_fused_path_warns_for_nonfinite_steps_between_logging_points(caplog, tmp
     assert msgs == ["Non-finite style score at step 3", "Non-finite total loss at step 3, using previous loss",
                     "Non-finite content score at step 5", "Non-finite total loss at step 5, using previous loss",
                     "Non-finite style score at step 7", "Non-finite total loss at step 7, using previous loss"]
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_no_python_scalar_conversion_between_flushes(monkeypatch, fused):
+    """Reference tests/test_optimization.py:943-970: with log_every beyond the run length no closure may turn a
+    tensor into a Python scalar (`Tensor.item` patched to fail).  Here also `Tensor.tolist` - what this build's
+    flush uses - and for the fused path too (whose per-step finite checks happen at the flush, from the ring)."""
+    class Fused(nn.Module):
+        def loss_and_grad(self, x, style_w, content_w):
+            x.grad = 2 * x.detach()
+            s, c = (x.detach() ** 2).mean(), x.detach().mean() * 0
+            return s, c, style_w * s + content_w * c
+    x = _img()
+    cfg = _cfg(steps=3, log_every=50, save_every=100)
+    runner = OptimizationRunner(Fused() if fused else TinyModel(), x, cfg, optimizer=torch.optim.SGD([x], lr=0.5), progress_bar=Bar())
+    calls = []
+    real_tolist = torch.Tensor.tolist
+
+    def fail_item(_t):
+        raise AssertionError("tensor.item used during closure")
+
+    def counting_tolist(t):
+        calls.append(tuple(t.shape))
+        return real_tolist(t)
+    monkeypatch.setattr(torch.Tensor, "item", fail_item)
+    monkeypatch.setattr(torch.Tensor, "tolist", counting_tolist)
+    _, history, _ = runner.run()
+    monkeypatch.undo()
+    # nothing inside the loop; afterwards one transfer for the unchecked steps (fused path) and one for the history
+    assert len(history["total_loss"]) == 3
+    assert calls == ([(3, 3), (3, 3)] if fused else [(3, 3)]), calls
