@@ -83,6 +83,11 @@ def log_parameters(paths: InputPaths, cfg: stv_config.StyleTransferConfig) -> No
                 cfg.hardware.device, cfg.hardware.precision)
 
 
+def parse_int_list(s: str | list[int]) -> list[int]:
+    """``"0,1,2"`` or a list of ints -> list of ints (reference cli.py:303-314 re-exports config's helper)."""
+    return stv_config.parse_int_list(s)
+
+
 def run_from_args(args: argparse.Namespace) -> None:
     base_cfg = None
     if args.config:

@@ -149,26 +149,52 @@ def build_config_from_cli(
     else:
         cfg = StyleTransferConfig.model_validate({})
 
-    for key, (section, attr) in _DIRECT.items():
-        if key in args:
-            setattr(getattr(cfg, section), attr, args[key])
-    for key, (section, attr, value) in _FLAGS.items():
-        if args.get(key):
-            setattr(getattr(cfg, section), attr, value)
+    _apply_output_overrides(cfg, args)
+    _apply_optimization_overrides(cfg, args)
+    _apply_video_overrides(cfg, args)
+    _apply_hardware_overrides(cfg, args)
+    _enforce_csv_plot_rule(cfg)
+    return cfg
+
+
+def _apply_section(cfg: StyleTransferConfig, args: Mapping[str, Any], section: str) -> None:
+    """The table-driven part of one section: keys present in ``args`` overwrite, truthy flags set their value."""
+    for key, (sec, attr) in _DIRECT.items():
+        if sec == section and key in args:
+            setattr(getattr(cfg, sec), attr, args[key])
+    for key, (sec, attr, value) in _FLAGS.items():
+        if sec == section and args.get(key):
+            setattr(getattr(cfg, sec), attr, value)
+
+
+# Per-section entry points under the names the reference's own tests reach for (config.py:210-299 there).
+def _apply_output_overrides(cfg: StyleTransferConfig, args: Mapping[str, Any]) -> None:
+    _apply_section(cfg, args, "output")
+
+
+def _apply_optimization_overrides(cfg: StyleTransferConfig, args: Mapping[str, Any]) -> None:
+    _apply_section(cfg, args, "optimization")
     if args.get("style_layers"):
         cfg.optimization.style_layers = parse_int_list(args["style_layers"])
     if args.get("content_layers"):
         cfg.optimization.content_layers = parse_int_list(args["content_layers"])
+
+
+def _apply_video_overrides(cfg: StyleTransferConfig, args: Mapping[str, Any]) -> None:
+    _apply_section(cfg, args, "video")
     for key, attr in (("intro_duration", "intro_duration_seconds"), ("outro_duration", "outro_duration_seconds")):
         if key in args:
-            setattr(cfg.video, attr, max(args[key], 0.0))
+            setattr(cfg.video, attr, max(args[key], 0.0))       # negative durations mean "none"
     if "video_mode" in args:
         cfg.video.mode = args["video_mode"]
         cfg.video.mode_override = True
+    # a non-default mode that came from a TOML file / base config counts as an explicit choice too
     if not cfg.video.mode_override and cfg.video.mode != d.DEFAULT_VIDEO_MODE:
         cfg.video.mode_override = True
-    _enforce_csv_plot_rule(cfg)
-    return cfg
+
+
+def _apply_hardware_overrides(cfg: StyleTransferConfig, args: Mapping[str, Any]) -> None:
+    _apply_section(cfg, args, "hardware")
 
 
 def _enforce_csv_plot_rule(cfg: StyleTransferConfig) -> None:

@@ -24,6 +24,21 @@ from .logging_utils import logger
 VGG19_WEIGHTS_URL = "https://download.pytorch.org/models/vgg19-dcbb9e9d.pth"
 _PRECISIONS = {"fp32": torch.float32, "bf16": torch.bfloat16}
 
+# The two torchvision names the reference imports at module level (core_model.py:12) and its tests patch.  Without
+# torchvision (this image) ``vgg19`` is None - ``initialize_vgg`` then builds the same stack itself and loads the
+# cached checkpoint - and ``VGG19_Weights`` only carries the URL the cache file name is derived from.
+try:
+    from torchvision.models import VGG19_Weights, vgg19
+except ImportError:
+    vgg19 = None
+
+    class _WeightsEntry:
+        url = VGG19_WEIGHTS_URL
+
+    class VGG19_Weights:  # noqa: N801
+        IMAGENET1K_V1 = _WeightsEntry()
+        DEFAULT = IMAGENET1K_V1
+
 
 def resolve_precision(precision: str | None = None) -> torch.dtype:
     """Activation storage dtype: fp32 = parity mode (default), bf16 = performance mode."""
@@ -159,7 +174,7 @@ def initialize_vgg() -> nn.Module:
     ``STV_SYNTHETIC_WEIGHTS=<seed>`` is set (benchmarks / offline boxes).
     """
     cache_dir = Path(torch.hub.get_dir()) / "checkpoints"
-    cache_path = cache_dir / Path(urlparse(VGG19_WEIGHTS_URL).path).name
+    cache_path = cache_dir / Path(urlparse(VGG19_Weights.IMAGENET1K_V1.url).path).name
     synth = os.environ.get("STV_SYNTHETIC_WEIGHTS")
     if synth is not None:
         logger.info("Using synthetic VGG19 weights (seed %s)", synth)
@@ -170,10 +185,9 @@ def initialize_vgg() -> nn.Module:
             logger.info("Using cached VGG19 weights at %s", cache_path)
         else:
             logger.info("Downloading VGG19 weights to %s", cache_path)
-        try:
-            from torchvision.models import VGG19_Weights, vgg19  # noqa: PLC0415
+        if vgg19 is not None:       # torchvision's constructor - or whatever a caller put under that name
             vgg = vgg19(weights=VGG19_Weights.IMAGENET1K_V1).features
-        except ImportError:
+        else:
             if not cache_path.exists():
                 msg = (f"torchvision is not installed and {cache_path} is absent: place the IMAGENET1K_V1 "
                        "checkpoint there, or set STV_SYNTHETIC_WEIGHTS=<seed> for synthetic weights.")

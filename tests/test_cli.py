@@ -49,3 +49,93 @@ def test_validate_config_only(tmp_path):
     with pytest.raises(SystemExit) as e:
         cli.main(["--config", str(p), "--validate-config-only"])
     assert e.value.code == 0
+
+
+# ---- run_from_args driven with hand-made namespaces, as the reference's own tests do (tests/test_cli.py:209-852):
+# the namespaces there carry only SOME keys (no log_loss / log_every / no_plot ...), so every lookup must tolerate
+# absence, and the config that reaches main.style_transfer is what is pinned.
+import argparse
+import logging
+
+import torch
+
+from style_transfer_visualizer_amd import main as stv_main
+
+
+def _run(monkeypatch, **ns):
+    seen = {}
+
+    def fake_run(paths, cfg, **_kw):
+        seen["paths"], seen["cfg"] = paths, cfg
+        return torch.rand(1)
+    monkeypatch.setattr(stv_main, "style_transfer", fake_run)
+    monkeypatch.setattr(cli, "log_parameters", lambda *_a: None)
+    base = dict(content="cat.jpg", style="wave.jpg", config=None, validate_config_only=False,
+                compare_inputs=False, compare_result=False)
+    base.update(ns)
+    cli.run_from_args(argparse.Namespace(**base))
+    return seen
+
+
+def test_namespace_values_override_and_negative_durations_clamp(monkeypatch):
+    seen = _run(monkeypatch, output="out", steps=123, save_every=10, style_w=1.2, content_w=3.4, lr=0.5, fps=20,
+                init_method="white", no_normalize=False, no_video=False, final_only=True, quality=7, seed=123,
+                device="cpu", metadata_title="Title", metadata_artist="Artist", no_intro=False,
+                intro_duration=-5.0, outro_duration=-5.0, create_gif=True, gif_include_intro=True,
+                gif_include_outro=True)
+    cfg = seen["cfg"]
+    assert seen["paths"].content_path == "cat.jpg" and seen["paths"].style_path == "wave.jpg"
+    assert (cfg.optimization.steps, cfg.optimization.init_method, cfg.optimization.normalize) == (123, "white", True)
+    assert (cfg.optimization.style_w, cfg.optimization.content_w, cfg.optimization.lr, cfg.optimization.seed) == (1.2, 3.4, 0.5, 123)
+    assert (cfg.video.create_video, cfg.video.final_only, cfg.video.fps, cfg.video.quality, cfg.video.save_every) == (True, True, 20, 7, 10)
+    assert (cfg.video.metadata_title, cfg.video.metadata_artist, cfg.video.intro_enabled) == ("Title", "Artist", True)
+    assert cfg.video.intro_duration_seconds == 0.0 and cfg.video.outro_duration_seconds == 0.0       # negative -> 0
+    assert (cfg.video.create_gif, cfg.video.gif_include_intro, cfg.video.gif_include_outro) == (True, True, True)
+    assert cfg.output.output == "out" and cfg.hardware.device == "cpu"
+
+
+def test_negating_flags_flip(monkeypatch):
+    cfg = _run(monkeypatch, no_normalize=True, no_video=True, final_only=False, no_intro=True)["cfg"]
+    assert cfg.optimization.normalize is False and cfg.video.create_video is False and cfg.video.intro_enabled is False
+
+
+def test_config_file_is_the_base_when_not_only_validating(monkeypatch, tmp_path):
+    p = tmp_path / "config.toml"
+    p.write_text('[output]\noutput = "config_out"\n[optimization]\nsteps = 123\nstyle_w = 1.0\ncontent_w = 1.0\nlr = 1.0\n'
+                 'init_method = "random"\nseed = 42\nnormalize = true\n[video]\nsave_every = 5\nfps = 15\nquality = 9\n'
+                 'create_video = true\nfinal_only = false\n[hardware]\ndevice = "cuda"\n')
+    cfg = _run(monkeypatch, config=str(p))["cfg"]
+    assert cfg.output.output == "config_out" and cfg.optimization.steps == 123 and cfg.optimization.seed == 42
+    assert cfg.video.fps == 15 and cfg.video.quality == 9 and cfg.hardware.device == "cuda"
+
+
+def test_csv_logging_disables_the_plot_with_a_warning(monkeypatch, caplog):
+    lg = logging.getLogger("style_transfer")
+    lg.addHandler(caplog.handler)
+    try:
+        with caplog.at_level(logging.WARNING, logger="style_transfer"):
+            cfg = _run(monkeypatch, no_plot=False, log_loss="losses.csv", log_every=10)["cfg"]
+    finally:
+        lg.removeHandler(caplog.handler)
+    assert cfg.output.plot_losses is False and cfg.output.log_loss == "losses.csv"
+    assert "Loss plotting is disabled because CSV logging is enabled" in caplog.text
+
+
+def test_no_plot_flag_and_its_absence(monkeypatch):
+    assert _run(monkeypatch, no_plot=True)["cfg"].output.plot_losses is False
+    assert _run(monkeypatch)["cfg"].output.plot_losses is True
+
+
+def test_main_reads_sys_argv_and_runs(monkeypatch):
+    import sys
+    monkeypatch.setattr(sys, "argv", ["prog", "--content", "c.jpg", "--style", "s.jpg"])
+    ran = {}
+    monkeypatch.setattr(cli, "run_from_args", lambda a: ran.update(content=a.content, style=a.style))
+    cli.main()
+    assert ran == {"content": "c.jpg", "style": "s.jpg"}
+
+
+def test_log_flags_and_int_lists():
+    args = cli.build_arg_parser().parse_args("--content a --style b --log-loss losses.csv --log-every 25".split())
+    assert args.log_loss == "losses.csv" and args.log_every == 25
+    assert cli.parse_int_list([1, 2, 3]) == [1, 2, 3] and cli.parse_int_list("0, 5,10") == [0, 5, 10]

@@ -233,3 +233,32 @@ def test_initialize_vgg_consumes_the_generator_like_torchvision_vgg19(monkeypatc
     core_model.initialize_vgg()
     got = core_model.initialize_input(torch.zeros(1, 3, 5, 7), "random")
     assert torch.equal(got.detach(), want)
+
+
+def test_initialize_vgg_goes_through_the_module_level_constructor(monkeypatch, tmp_path):
+    """Reference tests/test_core_model.py:225-245: ``core_model.vgg19`` / ``core_model.VGG19_Weights`` are
+    module-level names a caller can replace; the stack comes from ``vgg19(weights=IMAGENET1K_V1).features`` and is
+    returned frozen and in eval mode."""
+    from urllib.parse import urlparse
+
+    import torch
+    from torch import nn
+
+    from style_transfer_visualizer_amd import core_model
+    monkeypatch.delenv("STV_SYNTHETIC_WEIGHTS", raising=False)
+    monkeypatch.setattr(torch.hub, "get_dir", lambda: str(tmp_path))
+    calls = []
+
+    class Fake(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.features = nn.Sequential(nn.Conv2d(3, 4, 3, padding=1), nn.ReLU())
+
+    def fake_vgg19(weights=None):
+        calls.append(weights)
+        return Fake()
+    monkeypatch.setattr(core_model, "vgg19", fake_vgg19)
+    out = core_model.initialize_vgg()
+    assert calls == [core_model.VGG19_Weights.IMAGENET1K_V1]
+    assert urlparse(core_model.VGG19_Weights.IMAGENET1K_V1.url).path.endswith("vgg19-dcbb9e9d.pth")
+    assert not out.training and all(not p.requires_grad for p in out.parameters())
