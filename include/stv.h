@@ -124,6 +124,12 @@ int stv_conv_tune(int H, int W, int cin, int cout, int taps, int dtype, void* st
  * the table), STV_ERR_ARG on a malformed entry. */
 int stv_conv_tune_export(int* out7, int max_entries);
 int stv_conv_tune_import(const int* in7, int n_entries);
+
+/* Hint for the NEXT stv_conv_igemm* launch issued from this thread: `bytes` of weights that the conv launched AFTER
+ * it will read.  That next launch touches them (one 128-byte line per lane, between its main loop and its epilogue) so
+ * they are on chip when their own launch starts.  The caller clears the hint (NULL / 0) after the launch.  No
+ * counterpart in the reference (cuDNN / oneDNN own their weights' residency). */
+void stv_conv_next_weights(const void* w, size_t bytes);
 int stv_conv_igemm(const void* x, const void* w, const float* bias, const void* ref,
                    void* y, int H, int W, int cin, int cout, int taps, int flags,
                    int dtype, void* stream);

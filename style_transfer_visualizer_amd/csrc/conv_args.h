@@ -21,6 +21,10 @@ struct ConvArgs {
   // forward pass's arg-max byte map route_idx [H][W][cout] - MaxPool2d's backward without a pass of its own
   const void* route_idx = nullptr;
   void* route_out = nullptr;
+  // optional: weights of the conv that runs NEXT (stv_conv_next_weights).  Each lane touches one 128-byte line of
+  // them between its main loop and its epilogue, so that launch finds them on chip instead of in HBM.
+  const void* pf = nullptr;
+  uint32_t pf_bytes = 0;
 };
 
 // conv_ws.hip: weight-stationary persistent kernel for 3x3, Cin = 64, bf16 (the short-K layers).

@@ -503,6 +503,10 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
     }
   }
 
+  // the next conv's weights: one 128-byte line per lane (lines past the end: no traffic), consumed at the very end
+  const __amdgpu_buffer_rsrc_t rs_pf = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.pf), 0, (int)a.pf_bytes, 0x00020000);
+  const uint32_t pf_word = __builtin_amdgcn_raw_buffer_load_b32(rs_pf, ((uint32_t)blockIdx.x * C::THREADS + (uint32_t)tid) * 128u, 0, 0);
+
   // ---- epilogue, in registers ----------------------------------------------------------------
   // A lane holds, per (row block, 32-channel block), 4 groups of 4 consecutive channels of ONE
   // pixel.  fp32: each group is a 16-byte store as it is.  bf16: a group packs to 8 bytes;
@@ -733,6 +737,7 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
     }
   }
   STV_STAMP(4);
+  asm volatile("" ::"v"(pf_word));
 #endif
 }
 
@@ -772,8 +777,16 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs a) {
   elem_traits<T>::store(yout + idx, s);
 }
 
+// Hint of the caller (the op-program executor): the weights the NEXT conv launch will read.  Consumed by the one
+// launch that follows on this thread.
+thread_local const void* g_next_w = nullptr;
+thread_local uint32_t g_next_w_bytes = 0;
+
 template <typename C>
-int launch_cfg(const ConvArgs& a, hipStream_t st) {
+int launch_cfg(const ConvArgs& a_in, hipStream_t st) {
+  ConvArgs a = a_in;
+  a.pf = g_next_w;
+  a.pf_bytes = g_next_w ? g_next_w_bytes : 0;
   const bool relu = (a.flags & STV_RELU_IN) != 0;
   const void* fn = relu ? reinterpret_cast<const void*>(&conv_igemm_kernel<C, true>)
                         : reinterpret_cast<const void*>(&conv_igemm_kernel<C, false>);
@@ -1107,6 +1120,11 @@ extern "C" int stv_conv_igemm_pool(const void* x, const void* w, const float* bi
   ConvArgs a{x, w, bias, nullptr, y, H, W, cin, cout, flags, y_pool, pool_idx, nullptr, nullptr, 0};
   hipStream_t st = static_cast<hipStream_t>(stream);
   return dtype == STV_F32 ? launch_typed<float, 9>(a, st) : launch_typed<bf16_t, 9>(a, st);
+}
+
+extern "C" void stv_conv_next_weights(const void* w, size_t bytes) {
+  g_next_w = (bytes > 0 && bytes < ((size_t)1 << 31)) ? w : nullptr;
+  g_next_w_bytes = g_next_w ? (uint32_t)bytes : 0;
 }
 
 extern "C" int stv_conv_igemm_route(const void* x, const void* w, const void* pool_idx, void* y_full, int H, int W, int cin,
