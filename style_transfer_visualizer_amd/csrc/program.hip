@@ -95,6 +95,21 @@ int run_op(const stv_op_t& op, void* st) {
   }
 }
 
+// A conv is told the weights of the next 3x3 conv and touches them on its way out (between main loop and
+// epilogue): that launch then finds them on chip.  Deep layers at 512^2: -1.5...-3.9 us per launch, step
+// 0.965 -> 0.936 ms.  STV_NEXT_W=0: off.  The caller clears the hint after the launch.
+void hint_next_weights(const std::vector<stv_op_t>& ops, size_t i) {
+  static const bool on = !(getenv("STV_NEXT_W") && atoi(getenv("STV_NEXT_W")) == 0);
+  if (!on || ops[i].op != STV_OP_CONV) return;
+  for (size_t j = i + 1; j < ops.size(); ++j) {
+    const stv_op_t& nx = ops[j];
+    if (nx.op == STV_OP_CONV && nx.taps == 9) {
+      stv_conv_next_weights(nx.p1, (size_t)9 * nx.cin * nx.cout * (nx.dtype == STV_BF16 ? 2 : 4));
+      return;
+    }
+  }
+}
+
 hipEvent_t next_event(stv_program* p, size_t& used) {
   if (used == p->events.size()) {
     hipEvent_t e = nullptr;
@@ -114,22 +129,10 @@ int run_all(stv_program* p, void* st, bool lanes) {
   if (lanes)
     for (const stv_op_t& o : p->ops) any_side |= (o.flags & STV_LANE_SIDE) != 0;
   if (!any_side) {
-    // A conv is told the weights of the next 3x3 conv and touches them on its way out (between main loop and
-    // epilogue): that launch then finds them on chip.  Deep layers at 512^2: -1.5...-3.9 us per launch, step
-    // 0.965 -> 0.936 ms.  STV_NEXT_W=0: off.
-    static const bool next_w = !(getenv("STV_NEXT_W") && atoi(getenv("STV_NEXT_W")) == 0);
     const size_t n_ops = p->ops.size();
     for (size_t i = 0; i < n_ops; ++i) {
       const stv_op_t& o = p->ops[i];
-      if (next_w && o.op == STV_OP_CONV) {
-        for (size_t j = i + 1; j < n_ops; ++j) {
-          const stv_op_t& nx = p->ops[j];
-          if (nx.op == STV_OP_CONV && nx.taps == 9) {
-            stv_conv_next_weights(nx.p1, (size_t)9 * nx.cin * nx.cout * (nx.dtype == STV_BF16 ? 2 : 4));
-            break;
-          }
-        }
-      }
+      hint_next_weights(p->ops, i);
       const int rc = run_op(o, st);
       stv_conv_next_weights(nullptr, 0);
       if (rc != STV_OK) return rc;
@@ -267,7 +270,11 @@ extern "C" int stv_program_profile_reps(stv_program* prog, void* stream, int rep
   int rc = STV_OK;
   (void)hipEventRecord(ev[0], st);
   for (size_t i = 0; i < n && rc == STV_OK; ++i) {
-    for (int k = 0; k < reps && rc == STV_OK; ++k) rc = run_op(prog->ops[i], stream);
+    for (int k = 0; k < reps && rc == STV_OK; ++k) {
+      hint_next_weights(prog->ops, i);             // the same launches the replayed step makes
+      rc = run_op(prog->ops[i], stream);
+      stv_conv_next_weights(nullptr, 0);
+    }
     (void)hipEventRecord(ev[i + 1], st);
   }
   if (hipStreamSynchronize(st) != hipSuccess) rc = STV_ERR_LAUNCH;
