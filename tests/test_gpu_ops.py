@@ -370,6 +370,33 @@ def test_conv_igemm_every_tile_config(dtype, cfg, case, monkeypatch):
     assert_close(ops.from_nhwc(out), ref2, dtype, 9 * cin, f"cfg {cfg} mask+accum {case}")
 
 
+@pytest.mark.parametrize("hint_bytes", [1, 100, 4096, 1 << 20, 5 << 20])
+def test_next_weights_hint_changes_nothing_but_timing(hint_bytes):
+    """stv_conv_next_weights: the launch that follows touches one 128-byte line per lane of the hinted range - fewer
+    lanes than lines, more lanes than lines, a range that ends inside a line - and its own result is bit-identical
+    to the launch without a hint; the hinted buffer is only read."""
+    from style_transfer_visualizer_amd import _lib
+    lib = _lib.load()
+    cin, cout, H, W = 64, 128, 24, 40
+    dtype = torch.bfloat16
+    x = ops.to_nhwc(rnd((1, cin, H, W), 91), dtype).to(DEV)
+    w = rnd((cout, cin, 3, 3), 92, -1, 1) * (2.0 / (9 * cin)) ** 0.5
+    wp = ops.block_weights(ops.pack_weights_fwd(w).to(dtype).to(DEV))
+    b = rnd((cout,), 93, -0.2, 0.2).to(DEV)
+    plain = ops.conv_igemm(x, wp, b, flags=ops.RELU_OUT).clone()
+    hinted = torch.arange(hint_bytes, device=DEV, dtype=torch.int64).to(torch.uint8)
+    before = hinted.clone()
+    lib.stv_conv_next_weights(hinted.data_ptr(), hint_bytes)
+    try:
+        got = ops.conv_igemm(x, wp, b, flags=ops.RELU_OUT)
+    finally:
+        lib.stv_conv_next_weights(None, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(got, plain)
+    assert torch.equal(hinted, before)
+    assert torch.equal(ops.conv_igemm(x, wp, b, flags=ops.RELU_OUT), plain)       # hint cleared: the plain launch again
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", CONV_CASES)
 @pytest.mark.parametrize("blocked", [False, True])
