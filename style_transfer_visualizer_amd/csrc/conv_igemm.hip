@@ -804,14 +804,16 @@ int launch_cfg(const ConvArgs& a_in, hipStream_t st) {
 // wave groups, 5 = 8x64 and 6 = 4x64 on a two-deep LDS ring (two / three workgroups per CU),
 // 7 = 2x64 with the K split (the 32x32-pixel layers: four times the workgroups of 4x64 x 2),
 // 8 = 1x64 with the K split in four-wave workgroups (a 32x32-pixel layer then covers all 256 CUs).  -1 = the shape is outside the matrix-core tiling (direct fallback).
-constexpr int kNumCfg = 11;     // 9 / 10 = 16x64 (four row blocks per wave: half the weight traffic per output) on the three- / two-deep ring
-const int kCfgTH[kNumCfg] = {8, 8, 4, 4, 4, 8, 4, 2, 1, 16, 16}, kCfgBN[kNumCfg] = {128, 64, 128, 64, 64, 64, 64, 64, 64, 64, 64};
+constexpr int kNumCfg = 13;     // 9 / 10 = 16x64 (four row blocks per wave: half the weight traffic per output) on the three- / two-deep ring
+// 11 = 2x32 with the K split (four waves: 2 rows x 2 K groups): on a 32x32-pixel layer still one workgroup per CU, which
+// stages 434 KB instead of 1x64's 694 KB;  12 = the same on 4 rows (eight waves)
+const int kCfgTH[kNumCfg] = {8, 8, 4, 4, 4, 8, 4, 2, 1, 16, 16, 2, 4}, kCfgBN[kNumCfg] = {128, 64, 128, 64, 64, 64, 64, 64, 64, 64, 64, 32, 32};
 
 bool cfg_valid(int cfg, int cout) { return cfg >= 0 && cfg < kNumCfg && !(cout <= 64 && kCfgBN[cfg] == 128); }
 // fp32 (parity mode) keeps a second accumulator set per K-stage (blocked summation): the eight-wave tiles with 64+
 // accumulator registers per lane (8x128, 16x64) would spill at their 256-register budget, so they are served by
 // the four-wave 4x128 tile (512 registers per wave) and the 8x64 tiles instead.
-int fp32_cfg(int cfg) { return cfg == 0 ? 2 : (cfg == 9 ? 1 : (cfg == 10 ? 5 : cfg)); }
+int fp32_cfg(int cfg) { return cfg == 0 ? 2 : (cfg == 9 ? 1 : (cfg == 10 ? 5 : (cfg == 11 ? 7 : (cfg == 12 ? 4 : cfg)))); }
 
 // Measured choices (stv_conv_tune), keyed by shape.
 struct TuneEntry { int H, W, cin, cout, taps, esize, cfg; };
@@ -881,6 +883,8 @@ int launch_mfma(const ConvArgs& a, int cfg, hipStream_t st) {
     case 8: return launch_cfg<Cfg<T, 1, 64, 1, 2, TAPS, 2>>(a, st);
     case 9: return launch_cfg<Cfg<T, 16, 64, 4, 2, TAPS>>(a, st);
     case 10: return launch_cfg<Cfg<T, 16, 64, 4, 2, TAPS, 1, 2>>(a, st);
+    case 11: return launch_cfg<Cfg<T, 2, 32, 2, 1, TAPS, 2>>(a, st);
+    case 12: return launch_cfg<Cfg<T, 4, 32, 4, 1, TAPS, 2>>(a, st);
     default: return launch_cfg<Cfg<T, 4, 64, 2, 2, TAPS>>(a, st);
   }
 }
@@ -890,7 +894,7 @@ int launch_typed(const ConvArgs& a, hipStream_t st) {
   // short-K layers (Cin = 64, bf16): weight-stationary persistent kernel (conv_ws.hip)
   if (stv_conv_ws_supported(a, elem_traits<T>::kDtype, TAPS)) return stv_conv_ws_launch(a, st);
   int cfg = choose_cfg(a.H, a.W, a.cin, a.cout, (int)sizeof(T), TAPS);
-  if ((cfg == 7 || cfg == 8) && a.pool != nullptr) cfg = 4;      // a 2-row tile holds one row per wave: no pooling window
+  if ((cfg == 7 || cfg == 8 || cfg == 11 || cfg == 12) && a.pool != nullptr) cfg = 4;      // one row per wave: no pooling window
   if (cfg < 0) {
     const size_t total = (size_t)a.H * a.W * a.cout;
     hipLaunchKernelGGL((conv_direct_kernel<T, TAPS>), dim3((unsigned)((total + 255) / 256)),
