@@ -385,6 +385,25 @@ __global__ __launch_bounds__(256) void gram_partial_bf16_multi_kernel(PartialMul
                              m.chunk[i], pair, ks);
 }
 
+// Taps of BOTH tile sizes in one grid (the 128-wide tiles first: they run longer): at 512^2 the 64-channel tap of
+// conv1_1 and the four wider taps were two launches of 10 + 16 us, latency-bound each.
+__global__ __launch_bounds__(256) void gram_partial_bf16_both_kernel(PartialMulti m128, PartialMulti m64) {
+  const int n128 = m128.block0[m128.n];
+  int pair, ks;
+  if ((int)blockIdx.x < n128) {
+    const int i = find_tap(m128.block0, m128.n, blockIdx.x);
+    decode_block(blockIdx.x - m128.block0[i], m128.pairs[i], m128.ksplit[i], pair, ks);
+    gram_partial_bf16_body<128>(static_cast<const bf16_t*>(m128.F[i]), m128.partials[i], m128.N[i], m128.C[i],
+                                m128.ksplit[i], m128.chunk[i], pair, ks);
+  } else {
+    const int b = (int)blockIdx.x - n128;
+    const int i = find_tap(m64.block0, m64.n, b);
+    decode_block(b - m64.block0[i], m64.pairs[i], m64.ksplit[i], pair, ks);
+    gram_partial_bf16_body<64>(static_cast<const bf16_t*>(m64.F[i]), m64.partials[i], m64.N[i], m64.C[i], m64.ksplit[i],
+                               m64.chunk[i], pair, ks);
+  }
+}
+
 // FIN_E consecutive Gram elements (512 bytes of every slab) per block: 32 lanes x one float4 each,
 // FIN_S ks-slices per element group, reduced through LDS in a fixed order (deterministic).  The
 // slab walk is latency- and dispatch-bound (a thread's whole job is a handful of loads), hence
@@ -620,7 +639,9 @@ extern "C" int stv_gram_multi(const stv_gram_tap_t* taps, int n_taps, int dtype,
     if (!t.partials || t.n_pixels <= 0 || t.channels <= 0 || t.channels % vec || t.norm <= 0.0f) return STV_ERR_ARG;
     if (dtype == STV_BF16 && (size_t)t.n_pixels * t.channels * 2 >= ((size_t)1 << 31)) return STV_ERR_ARG;
   }
-  // partial sums: one launch per tile size present
+  // partial sums: one launch per tile size present (bf16 with both sizes present: one launch for both)
+  static const bool merge_sizes = !(getenv("STV_GRAM_MERGE") && atoi(getenv("STV_GRAM_MERGE")) == 0);   // A/B aid
+  PartialMulti held{};                       // the 64-wide taps, waiting for the 128-wide ones
   for (int TS : {64, 128}) {
     PartialMulti m{};
     for (int i = 0; i < n_taps; ++i) {
@@ -636,7 +657,19 @@ extern "C" int stv_gram_multi(const stv_gram_tap_t* taps, int n_taps, int dtype,
       m.ksplit[k] = ksplit; m.chunk[k] = chunk; m.pairs[k] = pairs;
       m.block0[k + 1] = m.block0[k] + pairs * ksplit;
     }
+    if (dtype == STV_BF16 && merge_sizes && TS == 64 && m.n) {
+      bool wide = false;
+      for (int i = 0; i < n_taps; ++i) wide |= gram_tile(taps[i].channels) == 128 && taps[i].F != nullptr;
+      if (wide) { held = m; continue; }
+    }
     if (!m.n) continue;
+    if (dtype == STV_BF16 && TS == 128 && held.n) {
+      constexpr int lds = GramBCfg<128>::LDS_BYTES > GramBCfg<64>::LDS_BYTES ? GramBCfg<128>::LDS_BYTES : GramBCfg<64>::LDS_BYTES;
+      if (stv_set_max_lds(reinterpret_cast<const void*>(&gram_partial_bf16_both_kernel), lds) != STV_OK) return STV_ERR_LAUNCH;
+      hipLaunchKernelGGL(gram_partial_bf16_both_kernel, dim3(m.block0[m.n] + held.block0[held.n]), dim3(256), lds, st, m, held);
+      STV_CHECK_LAUNCH();
+      continue;
+    }
     const dim3 grid(m.block0[m.n]);
 #define STV_SET_LDS(kern, bytes)                                                                             \
   do {                                                                                                       \
