@@ -695,14 +695,17 @@ extern "C" int stv_gram_multi(const stv_gram_tap_t* taps, int n_taps, int dtype,
 #undef STV_SET_LDS
     STV_CHECK_LAUNCH();
   }
-  // finish: one launch per depth class - taps with hundreds of slabs walk them with 32 slices per
-  // element (1024-thread blocks), the others with 8
+  // finish: one launch (8 slices per element); with STV_GRAM_FIN_MERGE=0 taps with hundreds of slabs get a launch
+  // of their own that walks them with 32 slices per element (1024-thread blocks)
   for (int deep = 0; deep < 2; ++deep) {
     FinishMulti f{};
     for (int i = 0; i < n_taps; ++i) {
       const stv_gram_tap_t& t = taps[i];
       const int ksplit = stv_gram_ksplit(t.n_pixels, t.channels);
-      if ((ksplit >= 128 ? 1 : 0) != deep) continue;
+      // (one launch for all taps measured faster than a second, 1024-thread launch for the many-slab tap:
+      // 14 + 8 us -> ~15 us at 512^2; STV_GRAM_FIN_MERGE=0 restores the two classes)
+      static const bool one_finish = !(getenv("STV_GRAM_FIN_MERGE") && atoi(getenv("STV_GRAM_FIN_MERGE")) == 0);
+      if (((ksplit >= 128 && !one_finish) ? 1 : 0) != deep) continue;
       const int k = f.n++;
       f.partials[k] = t.partials; f.target[k] = t.target; f.gram_out[k] = t.gram_out; f.loss_part[k] = t.loss_part;
       f.sgrad[k] = t.sgrad; f.coef_dev[k] = t.coef_dev; f.C[k] = t.channels; f.TS[k] = gram_tile(t.channels);
