@@ -57,8 +57,9 @@ def conv_flops(meta) -> float:
 
 
 _CFG_NAMES = {0: "8, 128, 4, 2", 1: "8, 64, 4, 2", 2: "4, 128, 1, 4", 3: "4, 64, 2, 2", 4: "4, 64, 2, 2", 5: "8, 64, 4, 2", 6: "4, 64, 2, 2", 7: "2, 64, 2, 2", 8: "1, 64, 1, 2",
-              9: "16, 64, 4, 2", 10: "16, 64, 4, 2"}
-_CFG_KS = {0: "1, 3", 1: "1, 3", 2: "1, 3", 3: "1, 3", 4: "2, 3", 5: "1, 2", 6: "1, 2", 7: "2, 3", 8: "2, 3", 9: "1, 3", 10: "1, 2"}
+              9: "16, 64, 4, 2", 10: "16, 64, 4, 2", 11: "2, 32, 2, 1", 12: "4, 32, 4, 1"}
+_CFG_KS = {0: "1, 3", 1: "1, 3", 2: "1, 3", 3: "1, 3", 4: "2, 3", 5: "1, 2", 6: "1, 2", 7: "2, 3", 8: "2, 3", 9: "1, 3", 10: "1, 2",
+           11: "2, 3", 12: "2, 3"}      # (tests/test_abi.py keeps these two tables as long as the library's list of tiles)
 
 
 def kernel_group(meta, OP, dtype_code: int = 1, flags: int = 0) -> str | None:
@@ -74,6 +75,8 @@ def kernel_group(meta, OP, dtype_code: int = 1, flags: int = 0) -> str | None:
         if cfg < 0:
             return f"conv_direct_kernel<{elem}, {taps}>"
         relu = "true" if (flags & 1) else "false"                  # STV_RELU_IN: the ReLU-on-load instantiation
+        if cfg not in _CFG_NAMES:                                  # a tile this table does not know yet: still a name
+            return f"conv_igemm_kernel<tile {cfg}, {elem}, {taps}>, {relu}>"
         return f"conv_igemm_kernel<Cfg<{elem}, {_CFG_NAMES[cfg]}, {taps}, {_CFG_KS[cfg]}>, {relu}>"
     names = {OP["CONV_FIRST_FWD"]: "conv_first_fwd", OP["CONV_FIRST_DGRAD"]: "conv_first_dgrad",
              OP["POOL_FWD"]: "maxpool_fwd", OP["POOL_BWD"]: "maxpool_bwd", OP["GRAM_PARTIAL"]: "gram_partial",

@@ -130,6 +130,10 @@ int stv_conv_tune_import(const int* in7, int n_entries);
  * they are on chip when their own launch starts.  The caller clears the hint (NULL / 0) after the launch.  No
  * counterpart in the reference (cuDNN / oneDNN own their weights' residency). */
 void stv_conv_next_weights(const void* w, size_t bytes);
+
+/* Number of tile configurations stv_conv_config() can return (0 .. n-1): tools and the bench that name the kernel
+ * instantiation of a tile check their tables against it. */
+int stv_conv_num_configs(void);
 int stv_conv_igemm(const void* x, const void* w, const float* bias, const void* ref,
                    void* y, int H, int W, int cin, int cout, int taps, int flags,
                    int dtype, void* stream);

@@ -1126,6 +1126,8 @@ extern "C" int stv_conv_igemm_pool(const void* x, const void* w, const float* bi
   return dtype == STV_F32 ? launch_typed<float, 9>(a, st) : launch_typed<bf16_t, 9>(a, st);
 }
 
+extern "C" int stv_conv_num_configs(void) { return kNumCfg; }
+
 extern "C" void stv_conv_next_weights(const void* w, size_t bytes) {
   g_next_w = (bytes > 0 && bytes < ((size_t)1 << 31)) ? w : nullptr;
   g_next_w_bytes = g_next_w ? (uint32_t)bytes : 0;

@@ -74,3 +74,11 @@ def test_tile_table_round_trip_and_modes(monkeypatch):
     assert lib.stv_conv_tune_import(None, 0) == 0 and lib.stv_conv_tune_export(None, 0) == 0
     _lib._import_tile_table(lib)                                  # restore for the tests that follow
     assert lib.stv_conv_tune_export(None, 0) == n_before
+
+
+def test_bench_names_every_tile_configuration():
+    """bench.py maps a tile index to the kernel instantiation rocprofv3 reports: its tables must cover every tile the
+    library can choose (a new tile once crashed the bench with a KeyError)."""
+    import bench
+    n = _lib.load().stv_conv_num_configs()
+    assert sorted(bench._CFG_NAMES) == list(range(n)) and sorted(bench._CFG_KS) == list(range(n))
