@@ -10,7 +10,8 @@ def t(fn, n=20):
     for _ in range(n): fn()
     e1.record(); e1.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
-for (H, cout, relu, pool) in ((1024, 64, True, True), (512, 128, False, False), (1024, 64, False, False)):
+HH = int(os.environ.get("WS_H", "1024"))
+for (H, cout, relu, pool) in ((HH, 64, True, True), (HH // 2, 128, False, False), (HH, 64, False, False)):
     x = (torch.randn(H, H, 64, device=dev) * 0.5).bfloat16()
     w = ops.block_weights((torch.randn(9, cout, 64, device=dev) * 0.06).bfloat16())
     b = torch.zeros(cout, device=dev)
@@ -24,7 +25,7 @@ for (H, cout, relu, pool) in ((1024, 64, True, True), (512, 128, False, False), 
         us = t(lambda: ops.conv_igemm(x, w, b, out=y, flags=fl))
     gf = 2 * 9 * 64 * cout * H * H / 1e9
     print(f"diag={os.environ.get('STV_WS_DIAG','0')} fwd {H}^2 64->{cout} relu={relu} pool={pool}: {us:7.1f} us  {gf / us * 1e3:7.0f} TFLOP/s")
-H = 1024
+H = HH
 dy = (torch.randn(H, H, 64, device=dev) * 0.5).bfloat16(); z = (torch.randn(H, H, 64, device=dev)).bfloat16()
 wb = ops.block_weights((torch.randn(9, 64, 64, device=dev) * 0.06).bfloat16()); S = (torch.randn(64, 64, device=dev) * 0.01).bfloat16()
 out = torch.empty(H, H, 64, device=dev, dtype=torch.bfloat16)
