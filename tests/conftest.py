@@ -107,3 +107,10 @@ GOLDEN_CASES = [
 @pytest.fixture(params=GOLDEN_CASES)
 def golden_case(request) -> GoldenCase:
     return GoldenCase(request.param)
+
+
+@pytest.fixture(autouse=True)
+def _package_logger_propagates(monkeypatch):
+    """The package logger does not propagate (as the reference's); ``caplog`` listens on the root logger."""
+    from style_transfer_visualizer_amd.logging_utils import logger
+    monkeypatch.setattr(logger, "propagate", True)

@@ -294,3 +294,163 @@ def test_no_python_scalar_conversion_between_flushes(monkeypatch, fused):
     # nothing inside the loop; afterwards one transfer for the unchecked steps (fused path) and one for the history
     assert len(history["total_loss"]) == 3
     assert calls == ([(3, 3), (3, 3)] if fused else [(3, 3)]), calls
+
+
+# ---- behaviours the reference's own tests pin on private helpers and callbacks (tests/test_optimization.py) ---------
+class MemorySink:
+    def __init__(self):
+        self.frames = []
+
+    def append_data(self, frame):
+        self.frames.append(np.asarray(frame, dtype=np.uint8))
+
+    def close(self):
+        return None
+
+
+class CountingBar(Bar):
+    def __init__(self):
+        super().__init__()
+        self.postfix_calls = []
+
+    def set_postfix(self, d=None, refresh=True, **kw):
+        self.postfix_calls.append(d)
+        super().set_postfix(d, refresh, **kw)
+
+
+def _runner(cfg=None, **kw):
+    x = _img()
+    kw.setdefault("optimizer", torch.optim.Adam([x]))
+    kw.setdefault("progress_bar", Bar())
+    return OptimizationRunner(TinyModel(), x, cfg or _cfg(steps=1, log_every=1, save_every=1), **kw), x
+
+
+def test_prepare_image_for_output_without_normalisation_is_a_clamp():
+    """reference tests/test_optimization.py:133-139."""
+    from style_transfer_visualizer_amd import image_io
+    t = torch.rand(1, 3, 16, 16) * 3 - 1
+    out = image_io.prepare_image_for_output(t, normalize=False)
+    assert out.shape == t.shape and bool((out >= 0).all()) and bool((out <= 1).all())
+    inside = (t >= 0) & (t <= 1)
+    assert torch.equal(out[inside], t[inside])
+
+
+@pytest.mark.parametrize("opt_class", [torch.optim.Adam, torch.optim.LBFGS])
+def test_one_frame_and_one_postfix_for_one_saved_step(opt_class):
+    """reference :200-236: steps=1, save_every=1 -> exactly one appended frame, one progress postfix."""
+    x = _img()
+    bar, sink = CountingBar(), MemorySink()
+    r = OptimizationRunner(TinyModel(), x, _cfg(steps=1, log_every=1, save_every=1),
+                           optimizer=opt_class([x]), progress_bar=bar, video_writer=sink)
+    r.run()
+    assert len(sink.frames) == 1 and sink.frames[0].shape == (8, 8, 3) and sink.frames[0].dtype == np.uint8
+    assert len(bar.postfix_calls) == 1
+
+
+def test_gif_collector_gets_the_frames_and_the_intro_crossfade():
+    """reference :394-441: a gif collector alone (no video writer) receives frames; with an intro frame and
+    crossfade frames configured it gets those first."""
+    cfg = _cfg(steps=2, log_every=1, save_every=1)
+    cfg.video.create_video = False
+    cfg.video.create_gif = True
+    cfg.video.gif_include_intro = True
+    x = _img()
+    gif = MemorySink()
+    intro = np.zeros((8, 8, 3), dtype=np.uint8)
+    OptimizationRunner(TinyModel(), x, cfg, optimizer=torch.optim.Adam([x]), progress_bar=Bar(), gif_collector=gif,
+                       intro_last_frame=intro, intro_crossfade_frames=2).run()
+    assert len(gif.frames) == 2 + 2                     # two crossfade frames, then one frame per step
+
+
+def test_callbacks_fire_once_per_step():
+    """reference :653-684."""
+    started, ended = [], []
+    cb = OptimizationCallbacks(on_step_start=started.append, on_step_end=lambda m: ended.append(m.total_loss))
+    r, _ = _runner(callbacks=cb)
+    r.run()
+    assert started == [1] and len(ended) == 1 and ended[0] is not None
+
+
+def test_step_metrics_carry_floats_only_at_the_logging_interval():
+    """reference :686-723: (step, has values) = (1, F), (2, T), (3, F), (4, T) for log_every = 2."""
+    seen = []
+    cb = OptimizationCallbacks(on_step_end=lambda m: seen.append((m.step, m.total_loss is not None)))
+    r, _ = _runner(_cfg(steps=4, log_every=2, save_every=100), callbacks=cb)
+    r.run()
+    assert seen == [(1, False), (2, True), (3, False), (4, True)]
+
+
+def test_summary_is_silent_before_any_step(caplog):
+    """reference :725-742."""
+    r, _ = _runner()
+    caplog.set_level("INFO")
+    r._log_optimization_summary()
+    assert "Optimization finished" not in caplog.text
+
+
+def test_check_finite_debug_line_and_warning_texts(caplog):
+    """reference :972-1031: a DEBUG line naming the step; three WARNING texts for non-finite values."""
+    r, _ = _runner()
+    caplog.set_level("DEBUG", logger="style_transfer")
+    one = torch.ones(())
+    r._check_finite(one, one, one, step_idx=5)
+    assert "Step 5" in caplog.text
+    caplog.clear()
+    caplog.set_level("WARNING")
+    nan = torch.tensor(float("nan"))
+    r._check_finite(nan, nan, nan, step_idx=5)
+    for what in ("Non-finite style score", "Non-finite content score", "Non-finite total loss"):
+        assert what in caplog.text
+
+
+def test_no_frame_when_the_image_cannot_be_prepared(monkeypatch):
+    """reference :1033-1073: prepare_image_for_output -> None: nothing appended, no postfix."""
+    from style_transfer_visualizer_amd import image_io
+    monkeypatch.setattr(image_io, "prepare_image_for_output", lambda *a, **k: None)
+    bar, sink = CountingBar(), MemorySink()
+    r, _ = _runner(progress_bar=bar, video_writer=sink)
+    r._maybe_write_video_frame(opt_mod.StepMetrics(step=1, style_loss=1.0, content_loss=1.0, total_loss=1.0))
+    assert sink.frames == [] and bar.postfix_calls == []
+
+
+def test_video_frame_hook_and_postfix_on_a_saved_frame():
+    """reference :1075-1137."""
+    steps_seen = []
+    bar, sink = CountingBar(), MemorySink()
+    cb = OptimizationCallbacks(on_video_frame=lambda _frame, step: steps_seen.append(step))
+    r, _ = _runner(progress_bar=bar, video_writer=sink, callbacks=cb)
+    r._maybe_write_video_frame(opt_mod.StepMetrics(step=1, style_loss=1.0, content_loss=1.0, total_loss=1.0))
+    assert steps_seen == [1] and len(sink.frames) == 1 and len(bar.postfix_calls) == 1
+
+
+def test_record_losses_without_an_accumulator_returns_none():
+    """reference :1139-1163."""
+    r, _ = _runner()
+    r._loss_accumulator = None
+    t = opt_mod.StepTensors(step=1, style_score=torch.tensor(1.0), content_score=torch.tensor(1.0), total_loss=torch.tensor(1.0))
+    assert r._record_losses(t) is None
+
+
+def test_progress_postfix_falls_back_to_the_last_logged_values():
+    """reference :1165-1223: empty metrics + a previous logged loss -> that loss, formatted %.4f; nothing at all -> no call."""
+    from style_transfer_visualizer_amd.loss_accumulator import LoggedLoss
+    bar = CountingBar()
+    r, _ = _runner(progress_bar=bar)
+    r._update_progress_postfix(opt_mod.StepMetrics(step=1))
+    assert bar.postfix_calls == []
+    r._latest_logged = LoggedLoss(step=1, style_loss=1.5, content_loss=2.5, total_loss=3.5)
+    r._update_progress_postfix(opt_mod.StepMetrics(step=1))
+    assert bar.postfix_calls == [{"style": "1.5000", "content": "2.5000", "loss": "3.5000"}]
+
+
+def test_logging_error_callback_gets_the_csv_open_failure(tmp_path):
+    """reference :882-913: a CSV path that cannot be opened -> on_logging_error(exc), the run goes on with history."""
+    errors = []
+    cfg = _cfg(steps=2, log_every=1, save_every=100, log_loss=str(tmp_path / "no_such_dir" / "x" / "loss.csv"))
+    (tmp_path / "no_such_dir").write_text("a file where a directory is needed")
+    x = _img()
+    r = OptimizationRunner(TinyModel(), x, cfg, optimizer=torch.optim.Adam([x]), progress_bar=Bar(),
+                           callbacks=OptimizationCallbacks(on_logging_error=errors.append))
+    _, history, _ = r.run()
+    assert len(errors) == 1 and isinstance(errors[0], OSError)
+    assert len(history["total_loss"]) == 2
