@@ -262,3 +262,50 @@ def test_initialize_vgg_goes_through_the_module_level_constructor(monkeypatch, t
     assert calls == [core_model.VGG19_Weights.IMAGENET1K_V1]
     assert urlparse(core_model.VGG19_Weights.IMAGENET1K_V1.url).path.endswith("vgg19-dcbb9e9d.pth")
     assert not out.training and all(not p.requires_grad for p in out.parameters())
+
+
+def _fake_vgg19(monkeypatch):
+    from torch import nn
+
+    from style_transfer_visualizer_amd import core_model
+
+    class Fake(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.features = nn.Sequential(nn.Conv2d(3, 4, 3, padding=1), nn.ReLU())
+    monkeypatch.setattr(core_model, "vgg19", lambda weights=None: Fake())
+    return core_model
+
+
+def test_download_notice_when_the_checkpoint_is_absent(monkeypatch, tmp_path, caplog):
+    """reference tests/test_core_model.py:242-259: INFO "Downloading VGG19 weights to <hub>/checkpoints/<file>"."""
+    import logging
+    from pathlib import Path
+    from urllib.parse import urlparse
+
+    import torch
+    monkeypatch.delenv("STV_SYNTHETIC_WEIGHTS", raising=False)
+    core_model = _fake_vgg19(monkeypatch)
+    monkeypatch.setattr(torch.hub, "get_dir", lambda: str(tmp_path))
+    want = tmp_path / "checkpoints" / Path(urlparse(core_model.VGG19_Weights.IMAGENET1K_V1.url).path).name
+    caplog.set_level(logging.INFO, logger="style_transfer")
+    core_model.initialize_vgg()
+    assert any("Downloading VGG19 weights" in m and str(want) in m for m in caplog.messages)
+
+
+def test_cache_notice_when_the_checkpoint_is_present(monkeypatch, tmp_path, caplog):
+    """reference tests/test_core_model.py:261-281."""
+    import logging
+    from pathlib import Path
+    from urllib.parse import urlparse
+
+    import torch
+    monkeypatch.delenv("STV_SYNTHETIC_WEIGHTS", raising=False)
+    core_model = _fake_vgg19(monkeypatch)
+    monkeypatch.setattr(torch.hub, "get_dir", lambda: str(tmp_path))
+    cached = tmp_path / "checkpoints" / Path(urlparse(core_model.VGG19_Weights.IMAGENET1K_V1.url).path).name
+    cached.parent.mkdir(parents=True)
+    cached.touch()
+    caplog.set_level(logging.INFO, logger="style_transfer")
+    core_model.initialize_vgg()
+    assert any("Using cached VGG19 weights" in m and str(cached) in m for m in caplog.messages)
