@@ -95,3 +95,70 @@ def test_frame_uint8_truncates_on_host_tensors():
     f = image_io.frame_uint8(x, normalize=False)
     assert f.shape == (1, 6, 3) and f.dtype == np.uint8
     assert f[0, :, 0].tolist() == [0, 127, 254, 255, 255, 0]
+
+
+# ---- edge behaviours the reference's tests/test_image_io.py pins --------------------------------------------
+def test_load_image_gives_rgb_and_reports_bad_files(tmp_path):
+    """reference :27-45: RGB mode; a missing file -> FileNotFoundError; bytes that are no image -> OSError
+    "Error loading image"."""
+    import pytest
+    from PIL import Image
+
+    from style_transfer_visualizer_amd import image_io
+    p = tmp_path / "grey.png"
+    Image.new("L", (80, 70), 128).save(p)
+    img = image_io.load_image(str(p))
+    assert isinstance(img, Image.Image) and img.mode == "RGB" and img.size == (80, 70)
+    with pytest.raises(FileNotFoundError):
+        image_io.load_image(str(tmp_path / "nonexistent_image.jpg"))
+    bad = tmp_path / "bad.jpg"
+    bad.write_bytes(b"not an image data")
+    with pytest.raises(OSError, match="Error loading image"):
+        image_io.load_image(str(bad))
+
+
+def test_dimension_checks_raise_for_small_and_warn_for_large(caplog):
+    """reference :182-199."""
+    import pytest
+    from PIL import Image
+
+    from style_transfer_visualizer_amd import image_io
+    image_io.validate_image_dimensions(Image.new("RGB", (512, 512)))
+    with pytest.raises(ValueError, match="Image too small"):
+        image_io.validate_image_dimensions(Image.new("RGB", (32, 100)))
+    caplog.set_level("WARNING")
+    image_io.validate_image_dimensions(Image.new("RGB", (4000, 4000)))
+    assert "may slow processing" in caplog.text
+
+
+def test_denormalize_changes_values_and_keeps_batches():
+    """reference :99-110."""
+    import torch
+
+    from style_transfer_visualizer_amd import image_io
+    t = torch.randn(2, 3, 20, 20)
+    out = image_io.denormalize(t)
+    assert out.shape == t.shape and not torch.allclose(out, t)
+
+
+def test_prepare_for_output_clamps_sanitises_and_keeps_shape():
+    """reference :204-262: with and without normalisation the result is in [0, 1], batches keep their shape,
+    extreme values are clamped, NaN / +-inf are sanitised."""
+    import torch
+
+    from style_transfer_visualizer_amd import image_io
+    ramp = torch.tensor([[[-3.0, -2.0, -1.0], [0.0, 1.0, 2.0], [3.0, 4.0, 5.0]]]).view(1, 1, 3, 3).repeat(1, 3, 1, 1)
+    out = image_io.prepare_image_for_output(ramp, normalize=True)
+    assert out.shape == ramp.shape and float(out.min()) >= 0.0 and float(out.max()) <= 1.0
+    assert not torch.allclose(out, ramp.clamp(0, 1))                      # denormalised first, then clamped
+    plain = torch.tensor([[-0.5, 0.2, 0.7], [0.0, 1.0, 1.5]]).view(1, 1, 2, 3).repeat(1, 3, 1, 1)
+    assert torch.allclose(image_io.prepare_image_for_output(plain, normalize=False), plain.clamp(0, 1))
+    wild = torch.tensor([[-100.0, -50.0, 0.0], [1.0, 50.0, 100.0]]).view(1, 1, 2, 3).repeat(1, 3, 1, 1)
+    batch = torch.rand(2, 3, 10, 10)
+    for norm in (True, False):
+        for t in (wild, batch):
+            o = image_io.prepare_image_for_output(t, normalize=norm)
+            assert o.shape == t.shape and float(o.min()) >= 0.0 and float(o.max()) <= 1.0
+    bad = torch.tensor([[[[float("nan"), float("inf"), -float("inf")]]]]).repeat(1, 3, 1, 1)
+    o = image_io.prepare_image_for_output(bad, normalize=False)
+    assert bool(torch.isfinite(o).all()) and float(o.min()) >= 0.0 and float(o.max()) <= 1.0
