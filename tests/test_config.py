@@ -83,3 +83,65 @@ def test_config_file_through_loader_hook():
         return cfg.StyleTransferConfig.model_validate({"optimization": {"steps": 3}})
     c = cfg.build_config_from_cli({"config": "x.toml", "steps": 5}, loader=loader)
     assert seen == ["x.toml"] and c.optimization.steps == 5
+
+
+# ---- loader and section-model behaviours the reference's tests/test_config.py pins ----------------------------
+def _toml(tmp_path, text):
+    p = tmp_path / "cfg.toml"
+    p.write_text(text)
+    return str(p)
+
+
+def test_loader_missing_file_partial_and_empty_files(tmp_path):
+    """reference :86-104, :273-289: a missing file raises; missing sections / an empty file fall back to the defaults."""
+    from style_transfer_visualizer_amd import config_defaults as d
+    with pytest.raises(FileNotFoundError):
+        cfg.ConfigLoader.load(str(tmp_path / "nonexistent_file.toml"))
+    part = cfg.ConfigLoader.load(_toml(tmp_path, "[optimization]\nsteps = 42\n"))
+    assert part.optimization.steps == 42 and part.optimization.lr == d.DEFAULT_LEARNING_RATE
+    assert part.video.fps == d.DEFAULT_FPS and part.hardware.device == d.DEFAULT_DEVICE
+    assert part.video.outro_duration_seconds == d.DEFAULT_VIDEO_OUTRO_DURATION
+    empty = cfg.ConfigLoader.load(_toml(tmp_path, ""))
+    assert empty.optimization.steps == d.DEFAULT_STEPS and empty.video.quality == d.DEFAULT_VIDEO_QUALITY
+    assert empty.video.create_gif == d.DEFAULT_CREATE_GIF and empty.video.gif_include_intro == d.DEFAULT_GIF_INCLUDE_INTRO
+    assert empty.video.gif_include_outro == d.DEFAULT_GIF_INCLUDE_OUTRO
+    assert empty.output.output == d.DEFAULT_OUTPUT_DIR and empty.output.log_every == d.DEFAULT_LOG_EVERY
+
+
+def test_loader_rejects_wrong_types(tmp_path):
+    """reference :291-297."""
+    with pytest.raises(ValidationError):
+        cfg.ConfigLoader.load(_toml(tmp_path, '[optimization]\nsteps = "not_an_int"\n'))
+
+
+@pytest.mark.parametrize("model,field,value", [
+    ("OptimizationConfig", "seed", -42), ("OptimizationConfig", "steps", -5), ("OptimizationConfig", "content_w", -1.0),
+    ("VideoConfig", "fps", 100), ("VideoConfig", "fps", 0), ("VideoConfig", "quality", 0),
+])
+def test_section_models_name_the_offending_field(model, field, value):
+    """reference :106-226: the section models can be built on their own and their ValidationError names the field."""
+    with pytest.raises(ValidationError) as err:
+        getattr(cfg, model)(**{field: value})
+    assert field in str(err.value)
+
+
+def test_output_section_defaults_and_default_layers():
+    """reference :264-271, :300-305."""
+    from style_transfer_visualizer_amd import config_defaults as d
+    out = cfg.OutputConfig.model_validate({})
+    assert out.output == d.DEFAULT_OUTPUT_DIR and out.log_every == d.DEFAULT_LOG_EVERY
+    assert out.log_loss is None and out.plot_losses is True
+    c = cfg.StyleTransferConfig.model_validate({})
+    assert c.optimization.style_layers == list(d.DEFAULT_STYLE_LAYERS)
+    assert c.optimization.content_layers == list(d.DEFAULT_CONTENT_LAYERS)
+
+
+def test_base_config_with_a_non_default_mode_counts_as_an_explicit_choice():
+    """reference :228-238."""
+    from style_transfer_visualizer_amd import config_defaults as d
+    base = cfg.StyleTransferConfig.model_validate({})
+    base.video.mode = next(m for m in ("postprocess", "realtime") if m != d.DEFAULT_VIDEO_MODE)
+    base.video.mode_override = False
+    built = cfg.build_config_from_cli({}, base_config=base)
+    assert built.video.mode == base.video.mode and built.video.mode_override is True
+    assert base.video.mode_override is False                      # the base object is not touched
