@@ -11,6 +11,7 @@ import sys
 from . import config as stv_config
 from . import main as stv_main
 from .config_defaults import DEFAULT_LOG_EVERY
+from .constants import VIDEO_QUALITY_MAX, VIDEO_QUALITY_MIN
 from .logging_utils import logger
 from .type_defs import InputPaths
 
@@ -74,13 +75,34 @@ def build_arg_parser() -> argparse.ArgumentParser:
     return p
 
 
-def log_parameters(paths: InputPaths, cfg: stv_config.StyleTransferConfig) -> None:
-    o = cfg.optimization
-    logger.info("Content: %s | Style: %s | Output: %s", paths.content_path, paths.style_path, cfg.output.output)
-    logger.info("Steps %d, style_w %g, content_w %g, lr %g, init %s, seed %d, normalize %s", o.steps, o.style_w,
-                o.content_w, o.lr, o.init_method, o.seed, o.normalize)
-    logger.info("Style layers %s, content layers %s, device %s, precision %s", o.style_layers, o.content_layers,
-                cfg.hardware.device, cfg.hardware.precision)
+def log_parameters(paths: InputPaths, cfg: stv_config.StyleTransferConfig,
+                   args: argparse.Namespace | None = None) -> None:
+    """One INFO line per setting, "Label: value" (the labels of reference cli.py:247-300, which its tests grep for;
+    plus the two hardware settings this build adds)."""
+    def yes(flag: bool) -> str:
+        return "Yes" if flag else "No"
+
+    def on(flag: bool) -> str:
+        return "Enabled" if flag else "Disabled"
+    o, v = cfg.optimization, cfg.video
+    rows: list[tuple[str, object]] = [("Content image loaded", paths.content_path), ("Style image loaded", paths.style_path)]
+    if getattr(args, "config", None):
+        rows.append(("Loaded config from", args.config))
+    rows += [
+        ("Output Directory", cfg.output.output), ("Steps", o.steps), ("Save Every", v.save_every),
+        ("Style Weight", f"{o.style_w:g}"), ("Content Weight", f"{o.content_w:g}"), ("Learning Rate", f"{o.lr:g}"),
+        ("Style Layers", o.style_layers), ("Content Layers", o.content_layers),
+        ("FPS for Timelapse Video", v.fps), ("Video Quality", f"{v.quality} ({VIDEO_QUALITY_MIN}-{VIDEO_QUALITY_MAX} scale)"),
+        ("Initialization Method", o.init_method), ("Normalization", on(o.normalize)),
+        ("Video Creation", on(v.create_video)), ("Intro Duration (s)", f"{v.intro_duration_seconds:.2f}"),
+        ("Outro Duration (s)", f"{v.outro_duration_seconds:.2f}"),
+        ("GIF Export", on(v.create_gif)), ("GIF Intro Included", yes(v.gif_include_intro)),
+        ("GIF Outro Included", yes(v.gif_include_outro)), ("Video Mode", v.mode),
+        ("Loss Plotting", on(cfg.output.plot_losses)), ("Random Seed", o.seed),
+        ("Device", cfg.hardware.device), ("Precision", cfg.hardware.precision),
+    ]
+    for label, value in rows:
+        logger.info("%s: %s", label, value)
 
 
 def parse_int_list(s: str | list[int]) -> list[int]:
@@ -97,7 +119,7 @@ def run_from_args(args: argparse.Namespace) -> None:
             sys.exit(0)
     cfg = stv_config.build_config_from_cli(vars(args), base_config=base_cfg)
     paths = InputPaths(content_path=args.content, style_path=args.style)
-    log_parameters(paths, cfg)
+    log_parameters(paths, cfg, args)
     stv_main.style_transfer(paths, cfg)
     if args.compare_inputs or args.compare_result:
         logger.warning("Comparison grids are a presentation feature outside this build; skipped.")

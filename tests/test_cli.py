@@ -139,3 +139,42 @@ def test_log_flags_and_int_lists():
     args = cli.build_arg_parser().parse_args("--content a --style b --log-loss losses.csv --log-every 25".split())
     assert args.log_loss == "losses.csv" and args.log_every == 25
     assert cli.parse_int_list([1, 2, 3]) == [1, 2, 3] and cli.parse_int_list("0, 5,10") == [0, 5, 10]
+
+
+# ---- log_parameters: signature and the labels the reference's tests grep for (tests/test_cli.py:682-789) ----------
+def _params_log(caplog, cfg_dict=None, config_path=None):
+    import argparse
+    import logging
+
+    from style_transfer_visualizer_amd import config as stv_config
+    from style_transfer_visualizer_amd.type_defs import InputPaths
+    cfg = stv_config.StyleTransferConfig.model_validate(cfg_dict or {})
+    args = argparse.Namespace(content="cat.jpg", style="s.jpg", config=config_path)
+    with caplog.at_level(logging.INFO, logger="style_transfer"):
+        cli.log_parameters(InputPaths(content_path=args.content, style_path=args.style), cfg, args)
+    return caplog.messages
+
+
+def test_log_parameters_names_the_config_file_only_when_there_is_one(caplog):
+    msgs = _params_log(caplog, config_path="abc.toml")
+    assert any("Loaded config from: abc.toml" in m for m in msgs)
+    caplog.clear()
+    assert not any("Loaded config from:" in m for m in _params_log(caplog))
+
+
+def test_log_parameters_reports_gif_settings_and_layers(caplog):
+    msgs = _params_log(caplog, {"video": {"create_gif": True, "gif_include_intro": True, "gif_include_outro": True},
+                                "optimization": {"style_layers": [0, 5, 10], "content_layers": [21]}})
+    for want in ("GIF Export: Enabled", "GIF Intro Included: Yes", "GIF Outro Included: Yes",
+                 "Style Layers: [0, 5, 10]", "Content Layers: [21]"):
+        assert any(want in m for m in msgs), want
+
+
+def test_log_parameters_works_without_the_namespace(caplog):
+    import logging
+
+    from style_transfer_visualizer_amd import config as stv_config
+    from style_transfer_visualizer_amd.type_defs import InputPaths
+    with caplog.at_level(logging.INFO, logger="style_transfer"):
+        cli.log_parameters(InputPaths("a.png", "b.png"), stv_config.StyleTransferConfig.model_validate({}))
+    assert any("Content image loaded: a.png" in m for m in caplog.messages)
