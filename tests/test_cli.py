@@ -178,3 +178,23 @@ def test_log_parameters_works_without_the_namespace(caplog):
     with caplog.at_level(logging.INFO, logger="style_transfer"):
         cli.log_parameters(InputPaths("a.png", "b.png"), stv_config.StyleTransferConfig.model_validate({}))
     assert any("Content image loaded: a.png" in m for m in caplog.messages)
+
+
+def test_final_frame_compare_default_and_flag_and_outro_duration(monkeypatch):
+    """reference tests/test_cli.py:319-439: on by default; ``final_frame_compare=False`` in the namespace (what
+    --no-final-frame-compare stores) switches it off; --outro-duration overrides the default."""
+    from style_transfer_visualizer_amd import config_defaults as d
+    seen = {}
+    monkeypatch.setattr(stv_main, "style_transfer", lambda paths, cfg: seen.setdefault("cfgs", []).append(cfg) or torch.rand(1))
+    monkeypatch.setattr(cli, "log_parameters", lambda *a: None)
+    base = dict(content="cat.jpg", style="wave.jpg", config=None, validate_config_only=False, compare_inputs=False,
+                compare_result=False)
+    cli.run_from_args(argparse.Namespace(**base))
+    cli.run_from_args(argparse.Namespace(**base, final_frame_compare=False))
+    cli.run_from_args(argparse.Namespace(**base, outro_duration=3.5))
+    a, b, c = seen["cfgs"]
+    assert a.video.final_frame_compare is True and a.video.outro_duration_seconds == d.DEFAULT_VIDEO_OUTRO_DURATION
+    assert b.video.final_frame_compare is False
+    assert c.video.outro_duration_seconds == 3.5
+    parsed = cli.build_arg_parser().parse_args(["--content", "c", "--style", "s", "--no-final-frame-compare"])
+    assert parsed.final_frame_compare is False
