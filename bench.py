@@ -171,6 +171,7 @@ def run_gpu(args, rank: int, world: int, device: torch.device, size: int, steps:
 
     def fence():
         torch.cuda.synchronize(device)
+        marks["arrived"] = time.perf_counter()      # this rank's own clock, before it waits for the others
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(device)
@@ -181,6 +182,7 @@ def run_gpu(args, rank: int, world: int, device: torch.device, size: int, steps:
             marks["t0"] = fence()
         elif metrics.step == warmup_total + steps:
             marks["t1"] = fence()
+            marks["t1_own"] = marks["arrived"]
 
     if warmup_total == 0:
         marks["t0"] = fence()
@@ -189,6 +191,7 @@ def run_gpu(args, rank: int, world: int, device: torch.device, size: int, steps:
         callbacks=optimization.OptimizationCallbacks(on_step_end=on_end))
     out, _history, _ = runner.run()
     elapsed = marks["t1"] - marks["t0"]
+    elapsed_rank = marks["t1_own"] - marks["t0"]       # this rank's K steps alone (the line's time is the max over ranks, fences included)
     if world > 1:
         from style_transfer_visualizer_amd import parallel
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -198,7 +201,7 @@ def run_gpu(args, rank: int, world: int, device: torch.device, size: int, steps:
         gathered = parallel.gather_results([(rank, out.detach().contiguous())], world)
         assert len(gathered) == world and all(g is not None for g in gathered)
 
-    info = {"elapsed": elapsed, "prefill": prefill}
+    info = {"elapsed": elapsed, "elapsed_rank": elapsed_rank, "prefill": prefill}
     st = opt.device_state() if hasattr(opt, "device_state") else {}
     info["lbfgs"] = {k: st.get(k) for k in ("n_iter", "hist_len", "skip", "no_update")}
     if rank == 0 and hasattr(opt, "device_state"):
@@ -207,16 +210,24 @@ def run_gpu(args, rank: int, world: int, device: torch.device, size: int, steps:
         from style_transfer_visualizer_amd import ops
         m = int(st.get("hist_len") or 0)
         n_el = x.numel()
+        # on COPIES of the image, the gradient and the optimizer's state / history (the run's own state is what the
+        # per-op profile below and the caller still use); two gradients alternate so that y = g - g_prev is not zero
+        # (a repeated gradient takes the no-push path); the side stream starts behind the copies
         xs, gs = x.detach().clone(), x.grad.detach().clone()
+        gs2 = gs * 0.995 + 1e-3 * gs.abs().mean() * torch.randn_like(gs)
+        st_copy, work_copy = opt._dev_state.clone(), opt._work.clone()
         stream = torch.cuda.Stream(device=device)
+        stream.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(stream):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             for k in range(23):
                 if k == 3:
                     e0.record()
-                ops.lbfgs_step(xs, gs, opt._dev_state, opt._work, HISTORY_SIZE, HISTORY_SIZE, 1.0, compact=opt._compact)
+                ops.lbfgs_step(xs, gs if k % 2 == 0 else gs2, st_copy, work_copy, HISTORY_SIZE, HISTORY_SIZE, 1.0, compact=opt._compact)
             e1.record()
             e1.synchronize()
+        torch.cuda.current_stream(device).wait_stream(stream)
+        del st_copy, work_copy, xs, gs2
         ms = e0.elapsed_time(e1) / 20
         nbytes = (4 * m + 8) * n_el * 4
         info["lbfgs"].update(bytes=nbytes, ms=round(ms, 4), hbm_frac=round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -347,7 +358,8 @@ def run_spatial(args, rank: int, world: int, device: torch.device) -> dict:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    return {"elapsed": elapsed, "rows": rows, "mode": mode, "scores": [float(v) for v in shard.last_scores.cpu()]}
+    return {"elapsed": elapsed, "rows": rows, "mode": mode, "scores": [float(v) for v in shard.last_scores.cpu()],
+            "route": getattr(shard, "route", "eager")}
 
 
 def cpu_baseline(size: int, threads: int) -> dict:
@@ -443,16 +455,6 @@ def _tile_info() -> dict:
 STEADY_FILL, STEADY_STEPS = 100, 60        # history_size = 100: after 100 steps every step runs at m = 100
 
 
-def steady_state(args, device: torch.device, size: int, precision: str) -> dict:
-    """Throughput of the CONFIG, not of the ramp: BASELINE configs[1]/[2] are 300/500-step runs, so
-    >= 2/3 of their steps see a full L-BFGS history (m = 100) whatever --steps/--warmup the caller
-    chose for the headline line.  Fills the history with STEADY_FILL untimed steps, times STEADY_STEPS."""
-    e = run_gpu(args, 0, 1, device, size, STEADY_STEPS, STEADY_FILL, precision=precision, profile=False, prefill_history=False)
-    return {"steps_per_s": round(STEADY_STEPS / e["elapsed"], 2), "ms_per_step": round(1e3 * e["elapsed"] / STEADY_STEPS, 4),
-            "hist_len": e["lbfgs"].get("hist_len"), "fill_steps": STEADY_FILL, "timed_steps": STEADY_STEPS,
-            "precision": precision}
-
-
 def _free_port() -> int:
     import socket
     with socket.socket() as sk:
@@ -513,29 +515,83 @@ def main() -> None:
                 "data": "synthetic",
                 "config": {"workload": "single 3840x2160 image, Adam lr 1e-3, VGG19, row-strip partition "
                                        f"({info.get('mode', 'recomputed halos')}; BASELINE.json configs[4])",
-                           "parallelism": f"spatial x{world}", "rank0_rows": info["rows"]},
+                           "parallelism": f"spatial x{world}", "rank0_rows": info["rows"], "world_size": world,
+                           "route": info["route"] + (" (closure replayed as one captured graph)" if info["route"] == "graph" else
+                                                     " (closure issued segment by segment; STV_SPATIAL_GRAPH=1 opts a multi-rank run into the captured form)"),
+                           "dist_backend": args.dist_backend},
                 "scores": info["scores"]}))
         parallel.shutdown()
         return
-    info = run_gpu(args, rank, world, device, args.size, args.steps, args.warmup)
+    # N > 1 is BASELINE configs[3]: independent 1024x1024 pairs, one per GPU (no data-path collective).  The headline
+    # of a multi-GPU line is therefore the 1024x1024 workload; 512x512 (configs[1]) runs as an extra leg on the same ranks.
+    # N = 1 keeps configs[1] (512x512) as the headline and carries 1024x1024 as `extra_1024` / `roofline.step_1024`.
+    head_size = args.size if (world == 1 or args.size != 512) else 1024
+    info = run_gpu(args, rank, world, device, head_size, args.steps, args.warmup)
+    per_rank = [info["elapsed_rank"]]
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.zeros(world, device=device, dtype=torch.float64)
+        t[rank] = info["elapsed_rank"]
+        dist.all_reduce(t)
+        per_rank = [round(float(v), 6) for v in t.cpu()]
     extra = None
+    extra_512 = None
     steady = None
+    fp32 = None
+    if world > 1 and head_size != args.size and not args.no_extra:
+        e = run_gpu(args, rank, world, device, 512, args.steps, args.warmup, profile=False)
+        extra_512 = {"workload": "single 512x512 image per GPU (BASELINE configs[1]), same ranks", "steps": args.steps,
+                     "value": round(args.steps * world / e["elapsed"], 3), "ms_per_step": round(1e3 * e["elapsed"] / args.steps, 4)}
     if not args.no_extra and args.size == 512 and world == 1:
         k2, w2 = max(10, args.steps // 4), max(5, min(args.warmup, 100))
-        e = run_gpu(args, rank, world, device, 1024, k2, w2)
+        e1024 = run_gpu(args, rank, world, device, 1024, k2, w2)
         extra = {"workload": "single 1024x1024 image (BASELINE configs[2])", "steps": k2, "warmup": w2,
-                 "value": round(k2 / e["elapsed"], 3), "ms_per_step": round(1e3 * e["elapsed"] / k2, 4),
-                 "roofline": e.get("roofline"), "fwd_gram": e.get("fwd_gram"), "closure": e.get("closure"),
-                 "breakdown_ms": e.get("breakdown_ms"), "lbfgs": e.get("lbfgs")}
+                 "value": round(k2 / e1024["elapsed"], 3), "ms_per_step": round(1e3 * e1024["elapsed"] / k2, 4),
+                 "roofline": e1024.get("roofline"), "fwd_gram": e1024.get("fwd_gram"), "closure": e1024.get("closure"),
+                 "breakdown_ms": e1024.get("breakdown_ms"), "lbfgs": e1024.get("lbfgs")}
+        # the reference's own arithmetic (fp32 parity mode): throughput at a full history AND its closure against the
+        # fp32 matrix-core peak (v_mfma_f32_32x32x2_f32 runs at the fp32 vector rate, 157.3 TFLOP/s)
+        fp32 = run_gpu(args, rank, world, device, 512, STEADY_STEPS, STEADY_FILL, precision="fp32", prefill_history=False)
         steady = {"note": ("throughput with the L-BFGS history full (m = 100): the headline value and extra_1024 are "
                            "timed in that state themselves (history prefilled by untimed steps); the fp32 parity mode: "
                            f"{STEADY_FILL} untimed fill steps, then {STEADY_STEPS} timed steps through OptimizationRunner"),
                   "512x512_bf16": {"steps_per_s": round(args.steps / info["elapsed"], 2), "hist_len": info["lbfgs"].get("hist_len")},
                   "1024x1024_bf16": {"steps_per_s": extra["value"], "hist_len": extra["lbfgs"].get("hist_len")},
-                  "512x512_fp32_parity_mode": steady_state(args, device, 512, "fp32")}
+                  "512x512_fp32_parity_mode": {"steps_per_s": round(STEADY_STEPS / fp32["elapsed"], 2),
+                                               "ms_per_step": round(1e3 * fp32["elapsed"] / STEADY_STEPS, 4),
+                                               "hist_len": fp32["lbfgs"].get("hist_len"), "fill_steps": STEADY_FILL,
+                                               "timed_steps": STEADY_STEPS, "precision": "fp32"}}
+
+    def step_summary(e: dict, steps_per_s: float) -> dict:
+        """The three yardsticks of one workload, for the `roofline` object (the driver's record keeps that object)."""
+        out = {"steps_per_s": round(steps_per_s, 2)}
+        if e.get("fwd_gram"):
+            out.update(fwd_gram_ms=e["fwd_gram"]["ms"], fwd_gram_hbm_frac=e["fwd_gram"]["hbm_frac"])
+        if e.get("closure"):
+            out.update(closure_ms=e["closure"]["ms"], closure_mfma_frac=e["closure"]["mfma_frac"])
+        if e.get("lbfgs") and e["lbfgs"].get("ms") is not None:
+            out.update(lbfgs_ms=e["lbfgs"]["ms"], lbfgs_hbm_frac=e["lbfgs"]["hbm_frac"])
+        if e.get("roofline"):
+            out.update(dominant_kernel=e["roofline"]["kernel"], dominant_frac=e["roofline"]["frac"],
+                       dominant_traffic=e["roofline"]["traffic"])
+        return out
 
     if rank == 0:
         total_steps = args.steps * world
+        roof = info.get("roofline")
+        if roof is not None:
+            roof[f"step_{head_size}"] = step_summary(info, args.steps / info["elapsed"])
+            if extra is not None:
+                roof["step_1024"] = step_summary(e1024, extra["value"])
+            if fp32 is not None and fp32.get("closure"):
+                cl = fp32["closure"]
+                roof["fp32_parity_mode"] = {
+                    "steps_per_s": round(STEADY_STEPS / fp32["elapsed"], 2), "closure_ms": cl["ms"],
+                    "tflops": round(cl["conv_gflop"] / cl["ms"], 2), "frac_of_157TF": cl["mfma_frac"],
+                    "fwd_gram_ms": fp32["fwd_gram"]["ms"], "fwd_gram_hbm_frac": fp32["fwd_gram"]["hbm_frac"],
+                    "note": "512x512, the reference's arithmetic (fp32 storage and sums): the mode that meets 1e-4 per pixel"}
+            roof["peaks"] = {"hbm_GBs": HBM_PEAK_GBS, "bf16_mfma_TFLOPs": BF16_PEAK_TFLOPS, "fp32_mfma_TFLOPs": FP32_PEAK_TFLOPS}
+        cfg_no = 1 if head_size == 512 else (3 if world > 1 else 2)
         line = {
             "metric": "optimization steps/sec at 512² and 1024², 1/2/4/8 MI355X",
             "value": round(total_steps / info["elapsed"], 3),
@@ -550,24 +606,29 @@ def main() -> None:
             "dtype": "bf16" if args.precision == "bf16" else "f32",
             "data": "synthetic",
             "config": {
-                "workload": (f"single {args.size}x{args.size} image per GPU, L-BFGS (max_iter=1, history 100), "
+                "workload": (f"single {head_size}x{head_size} image per GPU, L-BFGS (max_iter=1, history 100), "
                              f"VGG19 {args.precision} storage / fp32 accumulate, fp32 Gram, --no-video "
-                             "(BASELINE.json configs[1]); weights: synthetic He-scaled"),
-                "size": args.size, "images": world, "init_method": "random",
+                             f"(BASELINE.json configs[{cfg_no}]); weights: synthetic He-scaled"),
+                "size": head_size, "images": world, "init_method": "random",
                 "style_w": 1e5, "content_w": 1.0, "parallelism": f"replicas x{world} (independent images)",
                 "lbfgs_history_prefill_steps": info.get("prefill", 0),
                 "timed_region": "exactly --steps optimizer steps at a full L-BFGS history (m = 100), after --warmup untimed ones",
                 "world_size": world,
+                "per_rank_elapsed_s": per_rank,
                 "collectives": (f"RCCL {_rccl_version()} (torch.distributed backend "
                                 f"'{args.dist_backend}'): one all-gather of the final images after the timed region") if world > 1 else None,
+                "single_gpu_reference": ("this line's workload at N = 1 is `extra_1024.value` / `roofline.step_1024.steps_per_s` of the "
+                                         "`--gpus 1` line (whose headline is configs[1], 512x512)") if world > 1 and head_size == 1024 else None,
             },
             "tiles": _tile_info(),
-            "roofline": info.get("roofline"),
+            "roofline": roof,
             "fwd_gram": info.get("fwd_gram"),
             "closure": info.get("closure"),
             "breakdown_ms": info.get("breakdown_ms"),
             "lbfgs": info.get("lbfgs"),
         }
+        if extra_512 is not None:
+            line["extra_512"] = extra_512
         if steady is not None:
             line["steady_state"] = steady
         if extra is not None:
@@ -575,10 +636,10 @@ def main() -> None:
         if world == 1 and not args.no_cpu_baseline:
             cpu = host_cpu()
             # BASELINE.md §4 asks for the node's physical cores; on a many-core host the reference's CPU path is
-            # not fastest there (small convolutions, 128 threads), so a short probe also tries 32 and 16 threads and
+            # not fastest there (small convolutions, 128 threads), so a short probe also tries 64, 32, 16 and 8 threads and
             # the timed sample runs on whichever is fastest - every probed count is reported.
             probe = {}
-            for nt in sorted({cpu["threads"], min(32, cpu["threads"]), min(16, cpu["threads"])}, reverse=True):
+            for nt in sorted({cpu["threads"], *(min(k, cpu["threads"]) for k in (64, 32, 16, 8))}, reverse=True):
                 probe[nt] = cpu_probe(args.size, nt)
             threads = max(probe, key=probe.get)
             cpu["probe_steps_per_s"] = {str(k): round(v, 3) for k, v in probe.items()}

@@ -145,17 +145,48 @@ def _import_tile_table(lib: ctypes.CDLL) -> None:
     profile reproducible).  STV_CONV_TUNE=0 makes the library ignore the table (analytic choice); =1 re-measures
     shapes the table does not hold.  A missing file is fine: analytic choices."""
     import json  # noqa: PLC0415
+    import warnings  # noqa: PLC0415
     if not os.path.exists(TILE_TABLE_PATH):
         return
-    with open(TILE_TABLE_PATH) as fh:
-        doc = json.load(fh)
-    rows = [int(v) for e in doc.get("entries", []) for v in (e["H"], e["W"], e["cin"], e["cout"], e["taps"], e["elem_bytes"], e["cfg"])]
+
+    def give_up(why: str) -> None:
+        # a table the library cannot take (a tile index that no longer exists, a malformed entry, another device's
+        # measurements) must not make the package unusable: forget it and run on the analytic choices
+        lib.stv_conv_tune_import(None, 0)
+        tile_table_info.update(source=None, entries=0, ignored=f"{os.path.basename(TILE_TABLE_PATH)}: {why}")
+        warnings.warn(f"conv tile table {TILE_TABLE_PATH} ignored ({why}): analytic tile choices", RuntimeWarning, stacklevel=3)
+    try:
+        with open(TILE_TABLE_PATH) as fh:
+            doc = json.load(fh)
+        rows = [int(v) for e in doc.get("entries", []) for v in (e["H"], e["W"], e["cin"], e["cout"], e["taps"], e["elem_bytes"], e["cfg"])]
+    except (OSError, ValueError, KeyError, TypeError, AttributeError) as exc:
+        give_up(f"unreadable: {exc!r}")
+        return
     if not rows:
         return
+    arch = _device_arch()
+    measured_on = str(doc.get("arch") or "")
+    if arch is not None and measured_on and arch != measured_on:
+        give_up(f"measured on {measured_on}, this device is {arch}")
+        return
     arr = (c_int * len(rows))(*rows)
-    check(lib.stv_conv_tune_import(arr, len(rows) // 7), f"stv_conv_tune_import({TILE_TABLE_PATH})")
+    rc = lib.stv_conv_tune_import(arr, len(rows) // 7)
+    if rc != 0:
+        give_up(f"stv_conv_tune_import: {_ERRORS.get(rc, rc)}")
+        return
     tile_table_info.update(source=os.path.basename(TILE_TABLE_PATH), entries=len(rows) // 7, measured_on=doc.get("device"),
                            tool=doc.get("tool"))
+
+
+def _device_arch() -> str | None:
+    """gcnArchName of the current GPU ("gfx950"), or None when there is none (host-only use of the library)."""
+    import torch  # noqa: PLC0415
+    try:
+        if torch.cuda.device_count() == 0 or not torch.cuda.is_available():
+            return None
+        return str(torch.cuda.get_device_properties(torch.cuda.current_device()).gcnArchName).split(":")[0]
+    except (RuntimeError, AttributeError, AssertionError):
+        return None
 
 
 def export_tile_table() -> list[dict]:

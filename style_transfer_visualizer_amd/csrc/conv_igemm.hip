@@ -924,8 +924,17 @@ __global__ void tune_flush_kernel(uint4* p, size_t n) {
   }
 }
 
+// A measurement must not depend on a hint left for some other launch: cleared for the scope, restored after it.
+struct NextWeightsQuiet {
+  const void* w = g_next_w;
+  uint32_t bytes = g_next_w_bytes;
+  NextWeightsQuiet() { g_next_w = nullptr; g_next_w_bytes = 0; }
+  ~NextWeightsQuiet() { g_next_w = w; g_next_w_bytes = bytes; }
+};
+
 template <typename T>
 int tune_typed(int H, int W, int cin, int cout, int key_taps, hipStream_t st) {
+  const NextWeightsQuiet quiet;
   const bool route = key_taps == kRouteTaps;       // (bf16 only: the caller checked)
   const int taps = route ? 9 : key_taps;
   const size_t nx = (size_t)H * W * cin, nw = (size_t)taps * cout * cin, ny = (size_t)H * W * cout * (route ? 4 : 1);

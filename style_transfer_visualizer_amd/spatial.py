@@ -244,11 +244,17 @@ class HaloShard:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._host_p2p = dist.is_initialized() and dist.get_backend(group) == "gloo"
         # Whole closure as ONE captured graph (the 27 program segments, the 26 halo exchanges and the Gram
-        # all-reduce in between): nothing is issued from Python while a step runs.  RCCL point-to-point and
-        # collectives are stream operations and capture like kernels; the gloo rehearsal stages rows through
-        # host memory and cannot.  STV_SPATIAL_GRAPH=0 keeps the eager segment-by-segment form.
+        # all-reduce in between): nothing is issued from Python while a step runs.  With ONE strip the graph holds
+        # kernels only and is the default (verified: replay bit-identical to the eager form).  With several strips
+        # it would hold RCCL point-to-point and collective operations, a route that has never run on two devices:
+        # there the eager segment-by-segment form is the default and the capture is opt-in (STV_SPATIAL_GRAPH=1);
+        # an opted-in capture that fails on ANY rank raises on EVERY rank (the outcome is agreed by an all-reduce
+        # on the eager path) instead of leaving some ranks replaying and others eager.  The gloo rehearsal stages
+        # rows through host memory and cannot be captured.  STV_SPATIAL_GRAPH=0: always eager.
         import os  # noqa: PLC0415
-        self._graph_ok = os.environ.get("STV_SPATIAL_GRAPH", "1") != "0" and not self._host_p2p
+        want = os.environ.get("STV_SPATIAL_GRAPH", "")
+        self._graph_forced = want == "1" and self.world > 1
+        self._graph_ok = (not self._host_p2p) and want != "0" and (self.world == 1 or want == "1")
         self._graph: torch.cuda.CUDAGraph | None = None
         self._graph_stream: torch.cuda.Stream | None = None
         dev = content_img.device
@@ -435,15 +441,29 @@ class HaloShard:
             return self._closure_eager()
         if self._graph is None:
             out = self._closure_eager()                      # warm-up, and this call's result
+            err: Exception | None = None
             try:
                 self._capture_closure()
-            except Exception as exc:  # noqa: BLE001 - a runtime that cannot capture a collective: stay eager
-                from .logging_utils import logger  # noqa: PLC0415
-                logger.warning("row-strip closure could not be captured as a graph (%s): running it segment by segment", exc)
+            except (RuntimeError, torch.AcceleratorError) as exc:   # a runtime that cannot capture this stream work
+                err = exc
+            ok = torch.tensor([0.0 if err is not None else 1.0], device=self.x_core.device)
+            if self.world > 1:                               # every rank replays, or none does
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+            if float(ok) < 1.0:
                 self._graph_ok, self._graph = False, None
+                if self._graph_forced:
+                    msg = f"STV_SPATIAL_GRAPH=1: the row-strip closure could not be captured on every rank ({err})"
+                    raise RuntimeError(msg) from err
+                from .logging_utils import logger  # noqa: PLC0415
+                logger.warning("row-strip closure could not be captured as a graph (%s): running it segment by segment", err)
             return out
         self._graph.replay()
         return self.scores[:3].clone()
+
+    @property
+    def route(self) -> str:
+        """``graph`` once the closure replays as one captured graph, ``eager`` while / when it runs segment by segment."""
+        return "graph" if self._graph is not None else "eager"
 
     def _capture_closure(self) -> None:
         torch.cuda.synchronize(self.x_core.device)

@@ -76,6 +76,38 @@ def test_tile_table_round_trip_and_modes(monkeypatch):
     assert lib.stv_conv_tune_export(None, 0) == n_before
 
 
+def test_a_table_the_library_rejects_is_ignored_not_fatal(monkeypatch, tmp_path):
+    """A tile table with an entry the library cannot take (a tile index that no longer exists), a malformed file or a
+    table measured on another architecture must not make the package unusable: a warning, an empty table, the
+    analytic choices (load() used to raise)."""
+    import json
+
+    import pytest
+
+    lib = _lib.load()
+    good = json.load(open(_lib.TILE_TABLE_PATH))
+    n_before = lib.stv_conv_tune_export(None, 0)
+    e = dict(good["entries"][0])
+    for name, doc in (("bad_cfg", {"entries": [dict(e, cfg=999)]}), ("bad_key", {"entries": [{"H": 1}]}), ("not_json", None)):
+        path = tmp_path / f"{name}.json"
+        path.write_text("{" if doc is None else json.dumps(doc))
+        monkeypatch.setattr(_lib, "TILE_TABLE_PATH", str(path))
+        with pytest.warns(RuntimeWarning, match="ignored"):
+            _lib._import_tile_table(lib)
+        assert lib.stv_conv_tune_export(None, 0) == 0 and _lib.tile_table_info["entries"] == 0
+        assert lib.stv_conv_config(e["H"], e["W"], e["cin"], e["cout"], e["taps"], _lib.STV_BF16) == e["analytic"]
+    other = tmp_path / "other_arch.json"
+    other.write_text(json.dumps(dict(good, arch="gfx942")))
+    monkeypatch.setattr(_lib, "TILE_TABLE_PATH", str(other))
+    monkeypatch.setattr(_lib, "_device_arch", lambda: "gfx950")
+    with pytest.warns(RuntimeWarning, match="gfx942"):
+        _lib._import_tile_table(lib)
+    assert lib.stv_conv_tune_export(None, 0) == 0
+    monkeypatch.undo()
+    _lib._import_tile_table(lib)                                  # restore for the tests that follow
+    assert lib.stv_conv_tune_export(None, 0) == n_before and _lib.tile_table_info["entries"] == n_before
+
+
 def test_bench_names_every_tile_configuration():
     """bench.py maps a tile index to the kernel instantiation rocprofv3 reports: its tables must cover every tile the
     library can choose (a new tile once crashed the bench with a KeyError)."""

@@ -9,12 +9,15 @@ synthetic weights seed 0, content seed 0, style seed 1, ``init_method=random`` o
 weights.  What is asserted:
 
 * integer bookkeeping, bit-exact: step ids 1..N, one closure per step, history length, the logging steps;
-* every 50 (512^2) / 250 (1024^2) steps the CPU oracle - rounding to bf16 exactly where the kernels do - is
+* every 100 steps the CPU oracle - rounding to bf16 exactly where the kernels do - is
   evaluated AT THE IMAGE THE HIP PATH HOLDS and must give the loss the HIP path logged for it (chaos-free:
   nothing is compared between two free-running trajectories);
 * the device L-BFGS state (``n_iter``, history length, skip / no-update flags) equals, at each of the first 110
   steps, that of an ``oracle.optim_ref.LbfgsRef`` twin fed the same gradients: the ramp to 100 pairs, the first
-  ten evictions; at the end ``hist_len == 100`` and ``n_iter == steps``;
+  ten evictions (1024^2: the twin runs in float64 on the device); at the end ``hist_len == 100`` and ``n_iter == steps``;
+* BASELINE configs[0] literally (256^2, ``--init content --steps 50 --seed 0 --no-video --final-only`` through
+  ``cli.main``, fp32 and bf16) and configs[4] at its real length (200 Adam steps at 3840x2160: whole image and four
+  row strips): ``test_configs0_literal_run_through_the_cli``, ``test_configs4_200_adam_steps``;
 * the run optimises: the loss falls and stays finite.
 
 The loss curves go to ``gpurun_out/r03_loss_curve_<size>_<precision>.csv`` (copied to ``profiles/``).
@@ -22,11 +25,14 @@ The loss curves go to ``gpurun_out/r03_loss_curve_<size>_<precision>.csv`` (copi
 from __future__ import annotations
 
 import os
+import socket
 import time
 
 import numpy as np
 import pytest
 import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
 
 from oracle import core_model_ref as ocm
 from oracle import optim_ref
@@ -52,7 +58,7 @@ class _Bar:
         return None
 
 
-@pytest.mark.parametrize("size,steps,every,precision", [(512, 300, 50, "bf16"), (512, 300, 50, "fp32"), (1024, 500, 250, "bf16")])
+@pytest.mark.parametrize("size,steps,every,precision", [(512, 300, 100, "bf16"), (512, 300, 100, "fp32"), (1024, 500, 100, "bf16")])
 def test_config_runs_at_full_length(size, steps, every, precision, monkeypatch):
     monkeypatch.setenv("STV_SYNTHETIC_WEIGHTS", "0")
     bf16 = precision == "bf16"
@@ -80,8 +86,8 @@ def test_config_runs_at_full_length(size, steps, every, precision, monkeypatch):
         seen.append((mt.step, mt.has_values))
         if mt.step % every == every - 1 or mt.step == steps - 1:
             images[mt.step + 1] = x.detach().cpu().clone()        # the image step (mt.step + 1) evaluates
-        if mt.step <= TWIN_STEPS and size <= 512:        # (1024^2: 35 s of host time for the same state machine)
-            grads.append(x.grad.detach().cpu().clone().view(-1))
+        if mt.step <= TWIN_STEPS:        # 1024^2: gradients stay on the device, the twin runs there (below)
+            grads.append(x.grad.detach().clone().view(-1))
             st = opt.device_state()
             dev_states.append((st["n_iter"], st["hist_len"], st["skip"], st["no_update"]))
     runner = optimization.OptimizationRunner(model, x, cfg, optimizer=opt, progress_bar=_Bar(),
@@ -104,17 +110,23 @@ def test_config_runs_at_full_length(size, steps, every, precision, monkeypatch):
     assert torch.isfinite(out).all()
 
     # ---- device L-BFGS state vs the oracle optimizer fed the same gradients (first 110 steps) -----------------------
-    twin_x = torch.zeros(n)
+    # The twin's state machine in float64 on the device (torch's own vector ops; the fp32 twin on the host cores took
+    # 12 s at 512^2 and 35 s at 1024^2 for the same integers), as tests/test_gpu_lbfgs_long.py does for large n; the
+    # fp32 host twin - bit-identical to torch.optim.LBFGS - is what configs[0]'s 50 steps and the fixtures are held to.
+    twin_dev, twin_dt = DEV, torch.float64
+    twin_x = torch.zeros(n, device=twin_dev, dtype=twin_dt)
     twin = optim_ref.LbfgsRef(twin_x, lr=1.0)
     zero = torch.tensor(0.0)
     for k, g in enumerate(grads):
         n_before = twin.n_iter
-        twin.step(lambda: (zero, g))
+        gk = g.to(twin_dt)
+        twin.step(lambda: (zero, gk))
         want = (twin.n_iter, len(twin.old_dirs), int(twin.n_iter == n_before), 0)
         assert dev_states[k][:3] == want[:3], f"{case} step {k + 1}: device state {dev_states[k]} vs oracle optimizer {want}"
         assert dev_states[k][3] == 0
-    assert size > 512 or (len(twin.old_dirs) == 100 and twin.n_iter == TWIN_STEPS)
-    del grads, twin
+    assert len(twin.old_dirs) == 100 and twin.n_iter == TWIN_STEPS
+    del grads, twin, twin_x
+    torch.cuda.empty_cache()
 
     # ---- the oracle at the same image --------------------------------------------------------------------
     fused = _fused_style_taps(model)
@@ -166,6 +178,298 @@ def test_config_runs_at_full_length(size, steps, every, precision, monkeypatch):
             for k in range(steps):
                 fh.write(f"{k + 1},{history['style_loss'][k]!r},{history['content_loss'][k]!r},{history['total_loss'][k]!r}\n")
     del model, x, opt, runner
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_configs0_literal_run_through_the_cli(precision, tmp_path, monkeypatch):
+    """BASELINE.json configs[0], literally: ``--content 256x256 --style 256x256 --steps 50 --init content --no-video
+    --final-only --seed 0`` through ``cli.main`` (``--init`` is argparse's prefix of ``--init-method``, reference
+    cli.py:108; the start image is ``content_img.clone()``, core_model.py:89-90; the loop and the L-BFGS tolerance
+    exits are optimization.py:162-202 driving torch.optim.LBFGS) - on the HIP path (``--device cuda``) in the
+    reference's arithmetic (fp32) and in bf16 storage.
+
+    The content start is the regime the random-start runs never see: the content loss starts at exactly zero, the
+    first gradients are small, and L-BFGS may take its ``max|g| <= 1e-7`` early return (step counted, image not
+    moved) or the ``g.d > -1e-9`` exit.  Asserted: step ids / closure count / history length / logged steps
+    bit-exact; the device optimizer's integer state (n_iter, history length, skip, no-update) equal at EVERY one of
+    the 50 steps to an ``LbfgsRef`` twin fed the same gradients; every 10 steps the oracle evaluated AT THE IMAGE THE
+    HIP PATH HOLDS gives the logged losses; the PNG is the clamped final image."""
+    from PIL import Image
+
+    from style_transfer_visualizer_amd import cli, image_io, main as stv_main
+    monkeypatch.setenv("STV_SYNTHETIC_WEIGHTS", "0")
+    steps, every, size = 50, 10, 256
+    bf16 = precision == "bf16"
+    case = f"configs[0] 256x256 x50 init content {precision}"
+    for name, seed in (("content", 0), ("style", 1)):
+        img = synthetic.synthetic_image(seed, size, size, normalize=False)[0].permute(1, 2, 0).mul(255).byte().numpy()
+        Image.fromarray(img).save(tmp_path / f"{name}.png")
+
+    seen, images, grads, dev_states, held = [], {}, [], [], {}
+    real_runner = optimization.OptimizationRunner
+
+    class Hooked(real_runner):
+        def __init__(self, model, x, config, **kw):
+            def on_end(mt):
+                seen.append((mt.step, mt.has_values))
+                if mt.step % every == every - 1 or mt.step == steps - 1:
+                    images[mt.step + 1] = x.detach().cpu().clone()          # the image step (mt.step + 1) evaluates
+                grads.append(x.grad.detach().cpu().clone().view(-1))
+                st = kw["optimizer"].device_state()
+                dev_states.append((st["n_iter"], st["hist_len"], st["skip"], st["no_update"]))
+            kw["callbacks"] = optimization.OptimizationCallbacks(on_step_end=on_end)
+            kw["progress_bar"] = _Bar()
+            super().__init__(model, x, config, **kw)
+            held.update(runner=self, model=model, x=x, opt=kw["optimizer"], cfg=config, x0=x.detach().cpu().clone())
+
+        def run(self):
+            held["result"] = super().run()
+            return held["result"]
+    monkeypatch.setattr(stv_main.optimization, "OptimizationRunner", Hooked)
+    out_dir = tmp_path / "out"
+    cli.main(["--content", str(tmp_path / "content.png"), "--style", str(tmp_path / "style.png"), "--steps", str(steps),
+              "--init", "content", "--device", "cuda", "--no-video", "--final-only", "--seed", "0", "--precision", precision,
+              "--output", str(out_dir)])
+    runner, model, opt, cfg = held["runner"], held["model"], held["opt"], held["cfg"]
+    oc = cfg.optimization
+    assert oc.init_method == "content" and oc.steps == steps and oc.seed == 0 and cfg.hardware.precision == precision
+    assert cfg.video.create_video is False and cfg.video.save_every == steps + 1          # --final-only, reference main.py:30-33
+
+    # ---- the start image is the content image, bit for bit (core_model.py:89-90) ------------------------------------
+    content = image_io.load_image_to_tensor(str(tmp_path / "content.png"), torch.device("cpu"), normalize=oc.normalize)
+    style = image_io.load_image_to_tensor(str(tmp_path / "style.png"), torch.device("cpu"), normalize=oc.normalize)
+    assert torch.equal(held["x0"], content)
+
+    # ---- integer bookkeeping: bit-exact -------------------------------------------------------------------------------
+    assert [s for s, _ in seen] == list(range(1, steps + 1))
+    assert [s for s, has in seen if has] == list(range(10, steps + 1, 10))
+    assert runner._closure_calls == steps
+    _out, history, _elapsed = held["result"]
+    assert len(history["total_loss"]) == len(history["style_loss"]) == len(history["content_loss"]) == steps
+    png = out_dir / "stylized_content_x_style.png"
+    assert png.is_file() and Image.open(png).size == (size, size)
+
+    # ---- device L-BFGS integer state vs the oracle optimizer fed the same gradients, all 50 steps ---------------------
+    twin_x = content.clone().view(-1)
+    twin = optim_ref.LbfgsRef(twin_x, lr=oc.lr)
+    zero = torch.tensor(0.0)
+    events = {"skip": 0, "no_update": 0}
+    for k, g in enumerate(grads):
+        n_before, x_before = twin.n_iter, twin_x.clone()
+        twin.step(lambda: (zero, g))
+        skip = int(twin.n_iter == n_before)
+        no_update = int(not skip and torch.equal(x_before, twin_x))
+        want = (twin.n_iter, len(twin.old_dirs), skip, no_update)
+        assert dev_states[k] == want, f"{case} step {k + 1}: device state {dev_states[k]} vs oracle optimizer {want}"
+        events["skip"] += skip
+        events["no_update"] += no_update
+    end = opt.device_state()
+    assert end["n_iter"] == twin.n_iter and end["hist_len"] == len(twin.old_dirs)
+
+    # ---- the oracle at the same image, every 10 steps -------------------------------------------------------------------
+    weights = synthetic.synthetic_conv_weights(0)
+    fused = _fused_style_taps(model)
+    oracle = ocm.OracleModel(ocm.vgg_program(weights, synthetic.VGG19_CFG), S_LAYERS, C_LAYERS, bf16_storage=bf16,
+                             fused_style_taps=fused if bf16 else None)
+    oracle.set_targets(style, content)
+    if bf16:      # same image, same (rounded) targets: see test_config_runs_at_full_length
+        oracle.content_targets = [t.float().cpu().contiguous() for t in model.content_targets]
+        oracle.style_targets = [t.float().cpu() for t in model.style_targets]
+    logged = {k + 1: [history["style_loss"][k], history["content_loss"][k], history["total_loss"][k]] for k in range(steps)}
+    ltol = 2e-3 if bf16 else 1e-4
+    worst = 0.0
+    for step, img in sorted(images.items()):
+        with torch.no_grad():
+            s_l, c_l = oracle(img)
+        s_ref, c_ref = float(torch.stack(s_l).sum()), float(torch.stack(c_l).sum())
+        t_ref = oc.style_w * s_ref + oc.content_w * c_ref
+        got = logged[step]
+        floor = (2e-3 if bf16 else 1e-6) * abs(t_ref)
+        for nm, wgt, a, b in (("style", oc.style_w, got[0], s_ref), ("content", oc.content_w, got[1], c_ref), ("total", 1.0, got[2], t_ref)):
+            if wgt * abs(a - b) > floor or nm == "total":
+                rel = abs(a - b) / max(abs(b), 1e-30)
+                worst = max(worst, rel)
+                assert rel <= ltol, f"{case} step {step}: {nm} loss {a!r} vs oracle at the same image {b!r} (tolerance {ltol:.1e})"
+    totals = [logged[k][2] for k in sorted(logged)]
+    assert all(np.isfinite(totals))
+    # the PNG is round(clamp(denormalised final image) * 255) (reference runtime/output.py:92-101, torchvision save_image)
+    final = image_io.prepare_image_for_output(held["x"].detach().cpu(), normalize=oc.normalize)[0]
+    want_png = final.mul(255).add(0.5).clamp(0, 255).permute(1, 2, 0).to(torch.uint8).numpy()
+    assert np.array_equal(np.asarray(Image.open(png).convert("RGB")), want_png)
+    moved = float((held["x"].detach().cpu() - content).abs().max())
+    record_parity(case, f"losses vs oracle at the same image, {len(images)} steps (rel)", worst, ltol,
+                  f"steps {sorted(images)}; total {totals[0]:.4e} -> {totals[-1]:.4e}; L-BFGS n_iter {end['n_iter']}, history "
+                  f"{end['hist_len']}, early returns {events['skip']}, no-descent exits {events['no_update']}; image moved by "
+                  f"{moved:.2e} (max); integer state equal to the oracle optimizer at all {steps} steps")
+    del model, opt, runner
+    held.clear()
+    torch.cuda.empty_cache()
+
+
+# ------------------------------------------------------------------------------------------------ configs[4]
+C4_H, C4_W, C4_STEPS, C4_MARKS, C4_LR = 2160, 3840, 200, (100, 200), 1e-3
+
+
+def _c4_inputs(dev):
+    content = synthetic.synthetic_image(0, C4_H, C4_W).to(dev)
+    style = synthetic.synthetic_image(1, 512, 512).to(dev)
+    x0 = torch.randn(1, 3, C4_H, C4_W, generator=torch.Generator().manual_seed(0)).to(dev)
+    return content, style, x0
+
+
+def _c4_strip_worker(rank: int, world: int, port: int, out_dir: str, q) -> None:
+    """One of the four row strips of configs[4] (fp32 parity mode), 200 Adam steps; all ranks share cuda:0 and exchange
+    their halo rows over gloo (on a node the same code runs over RCCL / xGMI, one strip per GPU)."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      STV_SYNTHETIC_WEIGHTS="0", STV_CONV_TUNE="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from style_transfer_visualizer_amd import spatial
+    dev = torch.device("cuda:0")
+    content, style, x0 = _c4_inputs(dev)
+    model = core_model.StyleContentModel(S_LAYERS, C_LAYERS, precision="fp32").to(dev)
+    targets = model._engine_for(style).capture_style(style)
+    shard = spatial.HaloShard(model._layers(), S_LAYERS, C_LAYERS, content, targets, dtype=torch.float32,
+                              style_w=1e5, content_w=1.0)
+    shard.set_image(x0)
+    out = {"rows": (shard.c0, shard.c1), "exchanges": shard.exchanges_per_closure, "scores": {}, "route": shard.route}
+    t0 = time.time()
+    for k in range(1, C4_STEPS + 1):
+        if k in C4_MARKS:                               # the image step k evaluates, on every rank; rank 0 keeps it
+            img = shard.gather_image()
+            if rank == 0:
+                np.save(os.path.join(out_dir, f"image_{k}.npy"), img.cpu().numpy())
+            del img
+        sc = shard.step("adam", lr=C4_LR)
+        if k in C4_MARKS:
+            out["scores"][k] = sc.cpu().numpy()
+            np.save(os.path.join(out_dir, f"grad_{k}_rank{rank}.npy"), shard.g_core.cpu().numpy())   # gradient AT that image
+    torch.cuda.synchronize()
+    out["seconds"] = time.time() - t0
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_configs4_200_adam_steps(tmp_path, monkeypatch):
+    """BASELINE.json configs[4] at its real length: ONE 3840x2160 image, 200 Adam steps (lr 1e-3; the injected-optimizer
+    path of the reference, optimization.py:104-125 / tests/test_optimization.py:178), (a) as FOUR row strips
+    (544/544/544/528 rows, one rank each, 26 one-row halo exchanges per closure, raw Gram sums all-reduced before the
+    clamp) in fp32 parity mode and (b) as a whole image on one GPU in bf16 storage through ``OptimizationRunner``.
+
+    * the images the strip run holds at steps 100 and 200 (gathered) are handed to the CPU oracle: the losses the
+      strips logged for them must be the oracle's (1e-5); at step 100 also the gradient (near-ties included, as in
+      tests/test_gpu_fullsize.py) - the whole 4K image in fp32 is 1.98 GiB per 64-channel activation, just inside the
+      32-bit buffer offsets, so this is also the largest-offset check of every kernel on the path;
+    * strip run vs whole image: at both images the unsharded fp32 HIP model gives the strips' scores (2e-5) and, at
+      step 100, each rank's own-rows gradient (2e-5 of scale) - the tolerance of tests/test_gpu_spatial.py;
+    * the bf16 whole-image run: step ids / closure count / history length bit-exact over 200 steps, loss falls,
+      and the loss it logged for its final image is the fp32 model's at that image up to bf16 storage (3e-2)."""
+    from style_transfer_visualizer_amd import optimizers, spatial
+    monkeypatch.setenv("STV_SYNTHETIC_WEIGHTS", "0")
+    case = "configs[4] 3840x2160 x200 Adam"
+    world = 4
+    assert [spatial.strip_rows(C4_H, r, world)[:2] for r in range(world)] == [(0, 544), (544, 1088), (1088, 1632), (1632, 2160)]
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    t0 = time.time()
+    procs = [ctx.Process(target=_c4_strip_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=800) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    strips_wall = time.time() - t0
+    assert [got[r]["rows"] for r in range(world)] == [(0, 544), (544, 1088), (1088, 1632), (1632, 2160)]
+    assert got[0]["exchanges"] == 26 and all(got[r]["route"] == "eager" for r in range(world))
+    for k in C4_MARKS:                                  # every rank formed the same scores (all-reduced raw sums)
+        for r in range(1, world):
+            assert np.array_equal(got[0]["scores"][k], got[r]["scores"][k])
+
+    # ---- the unsharded fp32 HIP model and the CPU oracle at the images the strip run held ----------------------------
+    content, style, x0 = _c4_inputs(DEV)
+    model = core_model.StyleContentModel(S_LAYERS, C_LAYERS, precision="fp32").to(DEV)
+    model.set_targets(style, content)
+    oracle = ocm.OracleModel(ocm.vgg_program(synthetic.synthetic_conv_weights(0), synthetic.VGG19_CFG), S_LAYERS, C_LAYERS)
+    oracle.set_targets(style.cpu(), content.cpu())
+    t_or = time.time()
+    for k in C4_MARKS:
+        img = torch.from_numpy(np.load(tmp_path / f"image_{k}.npy"))
+        assert torch.isfinite(img).all() and not torch.equal(img, x0.cpu())
+        x = img.to(DEV).requires_grad_(True)
+        s, c, t = model.loss_and_grad(x, 1e5, 1.0)
+        whole = np.asarray([float(s), float(c), float(t)])
+        strip = got[0]["scores"][k].astype(np.float64)
+        dev_sw = float(np.max(np.abs(strip - whole) / np.abs(whole)))
+        record_parity(case, f"step {k}: four strips vs the whole image, scores (rel)", dev_sw, 2e-5)
+        assert dev_sw <= 2e-5, f"step {k}: strips {strip} vs whole image {whole}"
+        if k == C4_MARKS[0]:
+            g = x.grad.detach().cpu()
+            gscale = float(g.abs().max())
+            worst = 0.0
+            for r in range(world):
+                c0, c1 = got[r]["rows"]
+                g_r = torch.from_numpy(np.load(tmp_path / f"grad_{k}_rank{r}.npy"))
+                worst = max(worst, float((g_r - g[:, :, c0:c1]).abs().max()) / gscale)
+            record_parity(case, f"step {k}: own-rows gradient of every strip vs the whole image (of scale)", worst, 2e-5)
+            assert worst <= 2e-5
+            s_ref, c_ref, t_ref, g_ref = ocm.loss_and_grad(oracle, img, 1e5, 1.0)
+            rms = float((g - g_ref).norm() / g_ref.norm())
+            tail = float((g[:, :, -64:] - g_ref[:, :, -64:]).norm() / g_ref[:, :, -64:].norm())   # the largest byte offsets
+            record_parity(case, f"step {k}: whole-image fp32 gradient vs CPU-fp32 oracle (rel rms)", rms, 4e-3,
+                          f"last 64 rows alone: {tail:.1e}; ReLU / pool near-ties included")
+            assert rms <= 4e-3 and tail <= 8e-3
+        else:
+            with torch.no_grad():
+                s_l, c_l = oracle(img)
+            s_ref, c_ref = torch.stack(s_l).sum(), torch.stack(c_l).sum()
+            t_ref = 1e5 * s_ref + 1.0 * c_ref
+        for nm, a, w, b in (("style", strip[0], whole[0], float(s_ref)), ("content", strip[1], whole[1], float(c_ref)),
+                            ("total", strip[2], whole[2], float(t_ref))):
+            rel = max(abs(a - b), abs(w - b)) / abs(b)
+            record_parity(case, f"step {k}: {nm} loss, strips and whole image vs oracle at the same image (rel)", rel, 1e-5)
+            assert rel <= 1e-5, f"step {k} {nm}: strips {a!r}, whole {w!r}, oracle {b!r}"
+        del x
+    oracle_s = time.time() - t_or
+    first = float(got[0]["scores"][C4_MARKS[0]][2])
+    last = float(got[0]["scores"][C4_MARKS[1]][2])
+    assert last < first
+
+    # ---- the whole image in bf16 storage, 200 Adam steps through the runner (injected optimizer) -------------------
+    cfg = stv_config.StyleTransferConfig.model_validate({})
+    cfg.optimization.steps, cfg.optimization.init_method = C4_STEPS, "random"
+    cfg.hardware.precision = "bf16"
+    cfg.video.create_video = False
+    model_b = core_model.StyleContentModel(S_LAYERS, C_LAYERS, precision="bf16").to(DEV)
+    model_b.set_targets(style, content)
+    xb = x0.clone().requires_grad_(True)
+    adam = optimizers.HipAdam([xb], lr=C4_LR)
+    seen = []
+    runner = optimization.OptimizationRunner(model_b, xb, cfg, optimizer=adam, progress_bar=_Bar(),
+                                             callbacks=optimization.OptimizationCallbacks(on_step_end=lambda mt: seen.append(mt.step)))
+    t_b = time.time()
+    out, history, _ = runner.run()
+    torch.cuda.synchronize()
+    wall_b = time.time() - t_b
+    assert seen == list(range(1, C4_STEPS + 1)) and runner._closure_calls == C4_STEPS
+    assert len(history["total_loss"]) == C4_STEPS and adam._t == C4_STEPS
+    totals = np.asarray(history["total_loss"])
+    assert np.isfinite(totals).all() and totals[-1] < totals[0] and torch.isfinite(out).all()
+    # the loss logged at step 200 belongs to the image BEFORE the 200th update: re-evaluate both models at the final image
+    s, c, t_bf = model_b.loss_and_grad(xb, 1e5, 1.0)
+    xf = xb.detach().clone().requires_grad_(True)
+    s, c, t_f32 = model.loss_and_grad(xf, 1e5, 1.0)
+    rel = abs(float(t_bf) - float(t_f32)) / abs(float(t_f32))
+    record_parity(case, "bf16 whole-image run, loss at its final image vs the fp32 model at that image (rel)", rel, 3e-2,
+                  f"bf16 storage against fp32; loss {totals[0]:.4e} -> {totals[-1]:.4e} over {C4_STEPS} steps in {wall_b:.1f} s; fp32 strips: "
+                  f"{first:.4e} (step {C4_MARKS[0]}) -> {last:.4e} (step {C4_MARKS[1]}), {C4_STEPS} steps in {got[0]['seconds']:.0f} s "
+                  f"({strips_wall:.0f} s with start-up), oracle {oracle_s:.0f} s")
+    assert rel <= 3e-2
+    del model, model_b, xb, xf, adam, runner
     torch.cuda.empty_cache()
 
 

@@ -5,9 +5,12 @@ weights - what only exists at full size (the tile configurations picked there, G
 
 Per size and precision: the five Gram targets, then one closure + three L-BFGS steps with the CPU
 oracle re-evaluated AT THE SAME IMAGE (chaos-free: reference optimization.py:286-327,
-core_model.py:297-328) - at every step at 512^2, at the first and the last evaluation at 1024^2, where
-one fp32 + float64 oracle evaluation costs ~25 s of host time - and at every step the device L-BFGS update
-against the oracle optimizer fed the same gradients.  fp32 = the parity mode (reference arithmetic); bf16 = the measured mode, against the
+core_model.py:297-328) - at every step at 512^2, at the first and the last evaluation at 1024^2 - and at every step
+the device L-BFGS update against the oracle optimizer fed the same gradients.  Float64 evaluations (5 s at 512^2,
+20-25 s at 1024^2 each) are spent where they carry information: at 512^2 the plain fp64 rows at the first and the last
+evaluation and the same-branch comparison at the last one (an image L-BFGS has moved); at 1024^2 ONE float64
+evaluation, on the HIP path's own branch at the first image, against the bound the 512^2 run and round 3 measured
+for the CPU path there (4.0e-7).  fp32 = the parity mode (reference arithmetic); bf16 = the measured mode, against the
 oracle that rounds to bf16 exactly where the kernels do (oracle/core_model_ref.py).
 
 Tolerances (measured values are printed in the parity table at the end of the run):
@@ -17,8 +20,9 @@ Tolerances (measured values are printed in the parity table at the end of the ru
   the reference's own CPU path with 1 and with 16 threads, or MKL and these kernels - differ by
   ~3e-4 of the gradient's scale at these sizes (measured: HIP vs CPU-fp32 2.7e-4 rms at 512^2).
   The yardstick is therefore the same algorithm in float64: the HIP gradient must be as close
-  to it as the reference's fp32 CPU path is (x3, floor 2e-5), the criterion
-  tests/test_gpu_model.py::test_every_step_matches_oracle_at_same_image applies at fixture sizes.
+  to it as the reference's fp32 CPU path is - at full size in the two-part form below (same branch: x2, floor
+  1e-6; plain rows: x4, floor GRAD_FLOOR = 2.5e-3); tests/test_gpu_model.py::test_every_step_matches_oracle_at_same_image
+  applies the plain criterion at fixture sizes.
   MFMA K-loops add the 9*Cin products of an output one after the other, oneDNN's kernels in 16
   SIMD lanes.  Round 3: the fp32 kernels sum every K-stage in a fresh accumulator (blocked summation,
   csrc/conv_igemm.hip) and every stored activation / gradient of the HIP path is now CLOSER to float64
@@ -137,18 +141,24 @@ def test_fullsize_closure_and_lbfgs_steps_match_oracle(size, precision, monkeypa
 
     nl = pu.n_program_layers(S_LAYERS, C_LAYERS)
 
-    def check_same_branch(tag: str, g, g_cpu, xc, dec_hip) -> None:
-        """(a) of the module docstring: accuracy with the discrete decisions held fixed."""
+    def check_same_branch(tag: str, g, g_cpu, xc, dec_hip, cpu_branch: bool = True) -> None:
+        """(a) of the module docstring: accuracy with the discrete decisions held fixed.  ``cpu_branch=False`` (1024^2)
+        skips the float64 evaluation on the CPU path's branch - 25 s that only produce the bound - and holds the HIP path
+        to 1e-6, 2.5x what the CPU path measured on its own branch there in round 3 (4.0e-7) and at 512^2 in this run."""
         dec_cpu = pu.oracle_decisions(oracle.program, xc, nl)
         flips = pu.count_flips(dec_hip, dec_cpu)
         x64 = xc.double()
         g64_h = ocm.loss_and_grad(pu.lock(oracle64, dec_hip), x64, STYLE_W, CONTENT_W)[3]
-        g64_c = ocm.loss_and_grad(pu.lock(oracle64, dec_cpu), x64, STYLE_W, CONTENT_W)[3]
         err_hip = float((g.double() - g64_h).norm() / g64_h.norm())
-        err_cpu = float((g_cpu.double() - g64_c).norm() / g64_c.norm())
-        record_parity(case, f"{tag} grad vs fp64 on the same branch (rel rms)", err_hip, max(2 * err_cpu, 1e-6),
-                      f"reference's CPU-fp32 path on its own branch: {err_cpu:.2e}; {flips} ReLU/pool decisions differ between the two fp32 paths")
-        assert err_hip <= max(2 * err_cpu, 1e-6), f"{case} {tag}: HIP {err_hip:.2e} vs CPU-fp32 {err_cpu:.2e} (same-branch float64)"
+        if cpu_branch:
+            g64_c = ocm.loss_and_grad(pu.lock(oracle64, dec_cpu), x64, STYLE_W, CONTENT_W)[3]
+            err_cpu = float((g_cpu.double() - g64_c).norm() / g64_c.norm())
+            bound, note = max(2 * err_cpu, 1e-6), f"reference's CPU-fp32 path on its own branch: {err_cpu:.2e}; "
+        else:
+            bound, note = 1e-6, "fixed bound (the CPU path on its own branch: 4.0e-7 here in round 3); "
+        record_parity(case, f"{tag} grad vs fp64 on the same branch (rel rms)", err_hip, bound,
+                      note + f"{flips} ReLU/pool decisions differ between the two fp32 paths")
+        assert err_hip <= bound, f"{case} {tag}: HIP {err_hip:.2e} on its own branch vs float64 (bound {bound:.1e})"
         g32_h = ocm.loss_and_grad(pu.lock(oracle, dec_hip), xc, STYLE_W, CONTENT_W)[3]
         mx = float((g - g32_h).abs().max() / g32_h.abs().max())
         record_parity(case, f"{tag} grad HIP vs CPU-fp32 given the HIP decisions, per pixel max (of scale)", mx, 1e-3)
@@ -179,12 +189,13 @@ def test_fullsize_closure_and_lbfgs_steps_match_oracle(size, precision, monkeypa
 
     def g64_at(xc):
         return None if oracle64 is None else ocm.loss_and_grad(oracle64, xc.double(), STYLE_W, CONTENT_W)[3]
-    ref0, g64_0 = ocm.loss_and_grad(oracle, x0, STYLE_W, CONTENT_W), g64_at(x0)
+    ref0 = ocm.loss_and_grad(oracle, x0, STYLE_W, CONTENT_W)
+    g64_0 = g64_at(x0) if size <= 512 else None       # (1024^2: the float64 time goes to the same-branch row below)
     check("step1 pinned-tiles", l_pin, g_pin, ref0, g64_0)
     check("step1 tuned-tiles", l_tun, g_tun, ref0, g64_0)
     del model_t, x_t
-    if not bf16:      # `model` was evaluated at x0 before the tuned twin was built: its activations are still those
-        check_same_branch("step1", g_pin, ref0[3], x0, dec0)
+    if not bf16 and size > 512:      # `model` was evaluated at x0 before the tuned twin was built: its activations are still those
+        check_same_branch("step1", g_pin, ref0[3], x0, dec0, cpu_branch=False)
 
     # ---- three L-BFGS steps: oracle at the same image, oracle optimizer fed the HIP gradients --------
     # The update is built from fp32 dot products over 0.8M / 3.1M elements, and from the second pair on
@@ -216,9 +227,9 @@ def test_fullsize_closure_and_lbfgs_steps_match_oracle(size, precision, monkeypa
         if size <= 512 or step == 3:
             xc = x.detach().cpu()
             ref_k = ocm.loss_and_grad(oracle, xc, STYLE_W, CONTENT_W)
-            # (1024^2: the float64 evaluation - 20 s - at step 1 only; losses against the fp32 oracle here)
-            check(f"step{step + 1}", losses, g, ref_k, g64_at(xc) if size <= 512 else None)
-            if not bf16 and step == 3 and size <= 512:       # (1024^2: the same-branch check at step 1 only - 70 s of float64 each)
+            # float64: plain rows at the first and the last evaluation of the 512^2 run; losses against the fp32 oracle everywhere
+            check(f"step{step + 1}", losses, g, ref_k, g64_at(xc) if (size <= 512 and step == 3) else None)
+            if not bf16 and step == 3 and size <= 512:       # same branch, both paths, at an image L-BFGS has moved
                 check_same_branch(f"step{step + 1}", g, ref_k[3], xc, pu.hip_decisions(model))
     print(f"{case}: oracle time {time.time() - t0:.0f} s")
     del model, x

@@ -95,11 +95,11 @@ def _run(case: str, n: int, history: int, compact: bool, shards: tuple[int, ...]
          extra_steps: int = 40) -> None:
     grad = _objective(n)
     dev = _Device(n, history, compact, shards)
-    x32 = torch.zeros(n)
-    # the float64 yardstick runs torch's own vector ops on the GPU for large n (same algorithm, same arithmetic
-    # width; on the host cores it was 50 of this test's 80 s at n = 3 x 512^2); the fp32 twin - the reference's
-    # arithmetic, bit-identical to torch.optim.LBFGS on CPU - stays on the CPU
+    # For large n both twins run torch's own vector ops on the GPU (same algorithm, same arithmetic width; on the host
+    # cores they were 50 + 25 of this test's 80 s at n = 3 x 512^2).  At n = 20,000 the fp32 twin - the reference's
+    # arithmetic, bit-identical to torch.optim.LBFGS on CPU - stays on the CPU.
     dev64 = DEV if n >= 500_000 else torch.device("cpu")
+    x32 = torch.zeros(n, device=dev64)
     x64 = torch.zeros(n, dtype=torch.float64, device=dev64)
     twin32 = optim_ref.LbfgsRef(x32, lr=1.0, history_size=history)
     twin64 = optim_ref.LbfgsRef(x64, lr=1.0, history_size=history)
@@ -124,7 +124,8 @@ def _run(case: str, n: int, history: int, compact: bool, shards: tuple[int, ...]
         g64 = g.to(dev64).double()
         len_before = len(twin32.old_dirs)
         newest = twin32.old_dirs[-1] if twin32.old_dirs else None
-        twin32.step(lambda: (zero, g.clone()))
+        g32 = g.to(dev64)
+        twin32.step(lambda: (zero, g32.clone()))
         twin64.step(lambda: (zero.double(), g64))
         dev.step(g)
         x_after = dev.image()
@@ -143,7 +144,7 @@ def _run(case: str, n: int, history: int, compact: bool, shards: tuple[int, ...]
         assert not (pushed and step in (ev_repeat, ev_tiny))
         # ---- the update each optimizer applied ----------------------------------------------------------
         u_dev = (x_after.double() - x_before.double())
-        u_32 = (x32 - b32).double()
+        u_32 = (x32 - b32).double().cpu()
         u_64 = (x64 - b64).cpu()
         scale = float(u_64.abs().max())
         if step in (ev_tiny, ev_flat):
@@ -169,7 +170,7 @@ def _run(case: str, n: int, history: int, compact: bool, shards: tuple[int, ...]
     x_end = dev.image().double()
     x64 = x64.cpu()
     dx = float((x_end - x64).abs().max() / x64.abs().max())
-    dx32 = float((x32.double() - x64).abs().max() / x64.abs().max())
+    dx32 = float((x32.cpu().double() - x64).abs().max() / x64.abs().max())
     note = (f"fp32 reference's own worst {worst_32:.1e}; worst device/reference ratio {worst_ratio:.2f}; {steps} steps, "
             f"{pushes_after_full} evictions; final x vs float64 twin {dx:.1e} (reference {dx32:.1e})")
     record_parity(case, "L-BFGS update vs float64, worst step", worst_dev, max(4.0 * worst_32, 2e-6), note)

@@ -189,8 +189,14 @@ def test_trajectory_matches_reference(golden_case: GoldenCase, monkeypatch):
             dev = float(np.abs(got.numpy() - ref).max() / scale)
             tol = max(1e-4, 4.0 * sens)
             if not np.isfinite(tol) or tol > PIXEL_TOL_CAP:
-                record_parity(name, tag + what, dev, float("nan"),
-                              f"reported only: the reference's own spread here is {sens:.1e} of the range (x4 > {PIXEL_TOL_CAP:g})")
+                # An image the reference itself does not reproduce to 5e-2 of its range under 2-ulp gradient noise pins
+                # nothing at rounding level - but it is still bounded: 8x the reference's own spread, never more than the
+                # range itself (a regression that moved it tenfold fails; measured 2-4x).  Not counted as "compared".
+                ceiling = min(CEILING_SPREADS * sens, 1.0) if np.isfinite(sens) else 1.0
+                record_parity(name, tag + what, dev, ceiling,
+                              f"ceiling only ({CEILING_SPREADS:g}x the reference's own spread of {sens:.1e} of the range; x4 > {PIXEL_TOL_CAP:g}: no rounding-level claim)")
+                if not dev <= ceiling:
+                    bad.append(f"{tag}: {dev:.2e} > ceiling {ceiling:.2e}")
                 continue
             compared += 1
             record_parity(name, tag + what, dev, tol,
@@ -251,14 +257,30 @@ def test_trajectory_matches_reference(golden_case: GoldenCase, monkeypatch):
     rep_images = [xs.numpy() for xs in replay["x_steps"]] if "x_steps" in case.arrays else [replay["x"].numpy()]
     note = (f" [reference replayed on the HIP path's branch: at step {step_f} {flips} ReLU/pool decision(s) differ, "
             f"float64 gap <= {gap:.1e} of the layer rms]")
-    for row in rows:      # the plain comparison: reported (tolerance NaN), the replay rows below are the assertion
+    # The plain comparison across the flip is not a rounding-level claim (the replay rows below are), but it is BOUNDED:
+    # the reference's own arithmetic, moved onto the HIP path's branch by the same flipped decisions (`replay`), departs
+    # from the stored trajectory by some amount - this run may depart by at most twice that plus the row's tolerance.
+    own: dict[str, float] = {}
+    gold_total = np.asarray(golden_hist["total_loss"])
+    rep_total = np.asarray(rep_hist["total_loss"])
+    first = min(2, steps)
+    own[f"total loss, first {first} steps (rel)"] = float(np.abs(rep_total[:first] / gold_total[:first] - 1.0).max())
+    own[f"total loss, {steps} steps (rel)"] = float(np.abs(rep_total / gold_total - 1.0).max())
+    for (tag, _, ref, _), rep in zip(images, rep_images, strict=True):
+        own[tag] = float(np.abs(rep - ref).max() / float(np.abs(ref).max()))
+    over_ceiling = []
+    for row in rows:
         case_, qty, dev_, tol_, *rest = row
-        if tol_ != tol_:                                 # already a reported-only row
+        if dev_ <= tol_:
             emit(*row)
             continue
-        over = not dev_ <= tol_
-        emit(case_, qty, dev_, float("nan") if over else tol_,
-             (f"reported only - beyond {tol_:.1e} across the decision flip at step {step_f}: see the replayed rows" if over else (rest[0] if rest else "")))
+        ceiling = 2.0 * own.get(qty, 0.0) + tol_
+        emit(case_, qty, dev_, ceiling,
+             f"across the decision flip at step {step_f} (beyond the plain {tol_:.1e}): ceiling = 2x the reference arithmetic's own "
+             f"departure when the same decisions are flipped ({own.get(qty, float('nan')):.1e}) + the plain tolerance; the rounding-level rows are the replayed ones")
+        if not dev_ <= ceiling:
+            over_ceiling.append(f"{qty}: {dev_:.2e} > {ceiling:.2e}")
+    assert not over_ceiling, f"{name}: beyond what the flipped decisions explain: {over_ceiling}"
     bad2, rows2 = check(rep_hist, rep_images, note)
     for row in rows2:
         emit(*row)
@@ -267,6 +289,7 @@ def test_trajectory_matches_reference(golden_case: GoldenCase, monkeypatch):
 
 LOSS_TOL_CAP = 1e-2
 PIXEL_TOL_CAP = 5e-2
+CEILING_SPREADS = 8.0      # ceiling of an image row that is beyond PIXEL_TOL_CAP: this many times the reference's own spread
 
 
 def request_name(case: GoldenCase) -> str:
@@ -541,35 +564,6 @@ def test_4k_image_runs(monkeypatch):
     torch.cuda.empty_cache()
 
 
-def test_4k_whole_image_in_fp32_matches_the_oracle(monkeypatch):
-    """BASELINE configs[4]'s image (3840x2160) as ONE piece on one GPU in fp32 parity mode: its 64-channel
-    activations are 1.98 GiB - just inside the 32-bit buffer offsets of conv_igemm - so this exercises byte
-    offsets up to 2^31 in every kernel of the path.  Against the CPU oracle on the same image (26 s on the host
-    cores): losses to 1e-5, gradient to what ReLU / max-pool near-ties allow at 5e8 activations."""
-    monkeypatch.setenv("STV_SYNTHETIC_WEIGHTS", "0")
-    H, W = 2160, 3840
-    S_L, C_L = [0, 5, 10, 19, 28], [21]
-    content = synthetic.synthetic_image(0, H, W)
-    style = synthetic.synthetic_image(1, 512, 512)
-    x0 = torch.randn(1, 3, H, W, generator=torch.Generator().manual_seed(0))
-    model = core_model.StyleContentModel(S_L, C_L, precision="fp32").to(DEV)
-    model.set_targets(style.to(DEV), content.to(DEV))
-    x = x0.to(DEV).requires_grad_(True)
-    s, c, t = model.loss_and_grad(x, 1e5, 1.0)
-    got = (float(s), float(c), float(t))
-    g = x.grad.detach().cpu()
-    del model, x
-    torch.cuda.empty_cache()
-    oracle = ocm.OracleModel(ocm.vgg_program(synthetic.synthetic_conv_weights(0), synthetic.VGG19_CFG), S_L, C_L)
-    oracle.set_targets(style, content)
-    s_ref, c_ref, t_ref, g_ref = ocm.loss_and_grad(oracle, x0, 1e5, 1.0)
-    case = "configs[4] whole image 3840x2160 fp32"
-    for nm, a, b in (("style", got[0], float(s_ref)), ("content", got[1], float(c_ref)), ("total", got[2], float(t_ref))):
-        rel = abs(a - b) / abs(b)
-        record_parity(case, f"{nm} loss vs oracle (rel)", rel, 1e-5)
-        assert rel <= 1e-5, f"{nm}: {a!r} vs {b!r}"
-    rms = float((g - g_ref).norm() / g_ref.norm())
-    # bottom rows separately: the largest byte offsets
-    tail = float((g[:, :, -64:] - g_ref[:, :, -64:]).norm() / g_ref[:, :, -64:].norm())
-    record_parity(case, "gradient vs CPU-fp32 oracle (rel rms)", rms, 4e-3, f"last 64 rows alone: {tail:.1e}; ReLU / pool near-ties included")
-    assert rms <= 4e-3 and tail <= 8e-3
+# (The whole 3840x2160 image in fp32 against the CPU oracle - losses 1e-5, gradient incl. the last rows at the largest
+#  32-bit byte offsets - is part of tests/test_gpu_configs.py::test_configs4_200_adam_steps since round 4: there the
+#  image is the one the four-strip run holds after 100 Adam steps, and the strips are checked against it too.)

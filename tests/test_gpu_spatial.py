@@ -277,42 +277,5 @@ def test_halo_exchange_inside_a_subgroup_uses_global_peer_ranks():
         assert err < 2e-5, f"world rank {world_rank}: own-rows gradient differs by {err:.2e}"
 
 
-# ------------------------------------------------------------------------------ a configs[4] strip in fp32
-def test_4k_strip_in_fp32_matches_the_oracle(monkeypatch):
-    """One strip of BASELINE configs[4] as a problem of its own: 544 rows x 3840 columns (the height
-    strip_rows gives each of 4 ranks at 2160 rows), full-width VGG19, fp32 parity mode - 535-MB activations,
-    3840-pixel rows, the strip schedule (halo rows, pooling over own rows) - against the CPU oracle on the same
-    image: losses to 1e-5, gradient to what ReLU / max-pool near-ties allow (tests/parity_util.py)."""
-    from oracle import core_model_ref as ocm
-    from style_transfer_visualizer_amd import core_model, spatial, synthetic
-    from tests.conftest import record_parity
-    monkeypatch.setenv("STV_SYNTHETIC_WEIGHTS", "0")
-    assert spatial.strip_rows(2160, 0, 4)[:2] == (0, 544)
-    dev = torch.device("cuda:0")
-    Hs, Ws = 544, 3840
-    S_L, C_L = [0, 5, 10, 19, 28], [21]
-    content = synthetic.synthetic_image(0, Hs, Ws)
-    style = synthetic.synthetic_image(1, 512, 512)
-    x0 = torch.randn(1, 3, Hs, Ws, generator=torch.Generator().manual_seed(0))
-    model = core_model.StyleContentModel(S_L, C_L, precision="fp32").to(dev)
-    targets = model._engine_for(style.to(dev)).capture_style(style.to(dev))
-    shard = spatial.HaloShard(model._layers(), S_L, C_L, content.to(dev), targets, dtype=torch.float32, style_w=1e5, content_w=1.0)
-    shard.set_image(x0.to(dev))
-    scores = shard.loss_and_grad().cpu()
-    g = shard.g_core.cpu()
-    weights = synthetic.synthetic_conv_weights(0)
-    oracle = ocm.OracleModel(ocm.vgg_program(weights, synthetic.VGG19_CFG), S_L, C_L)
-    oracle.set_targets(style, content)
-    s_ref, c_ref, t_ref, g_ref = ocm.loss_and_grad(oracle, x0, 1e5, 1.0)
-    case = "configs[4] strip 544x3840 fp32"
-    for nm, a, b in (("style", float(scores[0]), float(s_ref)), ("content", float(scores[1]), float(c_ref)), ("total", float(scores[2]), float(t_ref))):
-        rel = abs(a - b) / abs(b)
-        record_parity(case, f"{nm} loss vs oracle (rel)", rel, 1e-5)
-        assert rel <= 1e-5
-    rms = float((g - g_ref).norm() / g_ref.norm())
-    frac = float(((g - g_ref).abs() > 2e-4 * g_ref.abs().max()).float().mean())
-    record_parity(case, "gradient vs CPU-fp32 oracle (rel rms)", rms, 3e-3,
-                  f"{frac:.1e} of the pixels beyond 2e-4 of scale: receptive fields of ReLU / pool near-ties")
-    assert rms <= 3e-3 and frac <= 6e-2
-    del model, shard
-    torch.cuda.empty_cache()
+# (configs[4]'s strips against the CPU oracle at full size - 544 / 528 x 3840 rows, fp32 - run in
+#  tests/test_gpu_configs.py::test_configs4_200_adam_steps: all four strips, 200 Adam steps, oracle at the gathered image.)

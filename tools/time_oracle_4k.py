@@ -1,5 +1,5 @@
 import os, sys, time
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, resource
 from oracle import core_model_ref as ocm
 from style_transfer_visualizer_amd import synthetic

@@ -1,5 +1,5 @@
 import os, sys, time
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["STV_SYNTHETIC_WEIGHTS"] = "0"
 import torch
 from style_transfer_visualizer_amd import core_model, synthetic, optimizers

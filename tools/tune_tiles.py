@@ -54,6 +54,7 @@ for key, cnt in sorted(votes.items()):
     entries.append(dict(H=H, W=W, cin=cin, cout=cout, taps=taps, elem_bytes=eb, cfg=cfg, analytic=analytic,
                         votes={str(c): v for c, v in sorted(cnt.items())}))
 doc = {"tool": "tools/tune_tiles.py", "rounds": args.rounds, "device": torch.cuda.get_device_name(0),
+       "arch": str(torch.cuda.get_device_properties(0).gcnArchName).split(":")[0],
        "date": datetime.date.today().isoformat(), "entries": entries}
 with open(args.out, "w") as fh:
     json.dump(doc, fh, indent=1)
