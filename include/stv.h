@@ -48,7 +48,8 @@ enum {
   STV_ACCUM = 8,     /* out += result instead of out = result */
   STV_W_BLOCKED = 16, /* conv weights are K-blocked: [taps][cin/CK][cout][CK], CK = 32 bytes of `dtype` */
   STV_POOL_IDX = 32,  /* stv_maxpool_bwd: `x` is the arg-max byte map of stv_conv_igemm_pool, not the activation */
-  STV_POOL_ROUTE = 64 /* stv_op_t only: the CONV op is stv_conv_igemm_route (p2 = arg-max map, q1 = routed output) */
+  STV_POOL_ROUTE = 64, /* stv_op_t only: the CONV op is stv_conv_igemm_route (p2 = arg-max map, q1 = routed output) */
+  STV_POOL_ONLY = 128  /* stv_conv_igemm_pool: do not store the full-resolution map `y` (only y_pool / pool_idx are wanted) */
 };
 
 int stv_version(void);
@@ -146,7 +147,11 @@ int stv_conv_igemm(const void* x, const void* w, const float* bias, const void* 
  * `pool_idx` (optional, [H/2][W/2][cout] bytes) receives what max_pool2d's backward needs
  * instead of the full-resolution activation: bits 0-1 = window position (2*dy + dx) of the
  * first maximum in scan order, bit 2 = that maximum is > 0 (the ReLU mask of the winner);
- * decided on the values as stored in `y`.  stv_maxpool_bwd takes it with STV_POOL_IDX. */
+ * decided on the values as stored in `y`.  stv_maxpool_bwd takes it with STV_POOL_IDX.
+ * STV_POOL_ONLY: `y` is not written (it may be NULL) - for a conv whose full-resolution output nobody reads again:
+ * the forward pass continues from `y_pool`, the backward pass routes through `pool_idx` (stv_conv_igemm_route /
+ * stv_maxpool_bwd with STV_POOL_IDX), so the pre-pool map - four times the pooled one - never has to reach HBM.
+ * The pooled map and the arg-max map are bit-identical to the ones written without the flag. */
 int stv_conv_igemm_pool(const void* x, const void* w, const float* bias, void* y, void* y_pool,
                         void* pool_idx, int H, int W, int cin, int cout, int flags, int dtype,
                         void* stream);

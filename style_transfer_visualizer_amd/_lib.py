@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STV_LIB_PATH") or os.path.join(_HERE, "libstv_hip.so")   # override: diagnostic builds
 
 STV_F32, STV_BF16 = 0, 1
-RELU_IN, RELU_OUT, MASK, ACCUM, W_BLOCKED, POOL_IDX, POOL_ROUTE = 1, 2, 4, 8, 16, 32, 64
+RELU_IN, RELU_OUT, MASK, ACCUM, W_BLOCKED, POOL_IDX, POOL_ROUTE, POOL_ONLY = 1, 2, 4, 8, 16, 32, 64, 128
 LANE_SIDE, LANE_JOIN = 1 << 29, 1 << 30          # scheduling hints of the command-buffer executor
 
 (OP_CONV_FIRST_FWD, OP_CONV_FIRST_DGRAD, OP_CONV, OP_POOL_FWD, OP_POOL_BWD, OP_RELU_FWD,

@@ -177,7 +177,9 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgrou
   const bool relu_out = (a.flags & STV_RELU_OUT) != 0;
   constexpr bool do_mask = DG && MASKED;
   const int out_bytes = a.H * a.W * a.cout * 2;
-  const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, out_bytes, 0x00020000);
+  // STV_POOL_ONLY (stv.h): nobody reads the full-resolution map again - a descriptor without records drops its stores
+  const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(
+      a.y, 0, (a.y != nullptr && !(POOL && (a.flags & STV_POOL_ONLY))) ? out_bytes : 0, 0x00020000);
 
   // ---- prologue: first two tiles in flight, weights in registers
   constexpr int NB = WsLds<DG>::NB;

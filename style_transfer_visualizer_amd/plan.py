@@ -27,7 +27,7 @@ import torch
 from torch import nn
 
 from . import _lib, ops
-from ._lib import (ACCUM, MASK, POOL_IDX, POOL_ROUTE, W_BLOCKED, OP_GRAM_MULTI, OP_CONTENT_GRAD, OP_CONTENT_LOSS, OP_CONV, OP_CONV_FIRST_DGRAD,
+from ._lib import (ACCUM, MASK, POOL_IDX, POOL_ONLY, POOL_ROUTE, W_BLOCKED, OP_GRAM_MULTI, OP_CONTENT_GRAD, OP_CONTENT_LOSS, OP_CONV, OP_CONV_FIRST_DGRAD,
                    OP_CONV_FIRST_FWD, OP_GRAM_FINISH, OP_GRAM_PARTIAL, OP_LOSS_COMBINE, OP_POOL_BWD,
                    OP_POOL_FWD, OP_RELU_BWD, OP_RELU_FWD, RELU_IN, RELU_OUT, StvOp)
 
@@ -45,6 +45,7 @@ class Buf:
     relu_fused: bool = False       # stored value is relu(z)
     taps: list = field(default_factory=list)
     grad: torch.Tensor | None = None
+    stored: bool = True            # False: the forward program does not write `act` (a pre-pool map nobody reads: STV_POOL_ONLY)
 
 
 @dataclass
@@ -272,6 +273,17 @@ class Schedule:
             elif nd.kind == "conv":
                 flags = ((RELU_IN if nd.relu_in else 0) | (RELU_OUT if d.relu_fused else 0)
                          | (W_BLOCKED if nd.wf.dim() == 4 else 0))
+                # The full-resolution map of a conv with the pool in its epilogue is dead in the bf16 step: the forward
+                # pass continues from the pooled map, the backward pass routes through the arg-max byte map (its bit 2 is
+                # the ReLU mask), and no tap sits on it - so it is not stored (conv1_2 at 1024^2: 134 MB of the
+                # kernel's 312; STV_SKIP_PREPOOL=0 stores it, e.g. for the tests that look at every stored tensor).
+                # fp32 (parity mode) keeps it: the parity tests read ReLU / arg-max decisions off the stored maps.
+                d.stored = True
+                if (pool_dst is not None and not d.taps and self.dtype == torch.bfloat16
+                        and (not self.with_grad or nxt.idx is not None)
+                        and os.environ.get("STV_SKIP_PREPOOL", "1") != "0"):
+                    flags |= POOL_ONLY
+                    d.stored = False
                 out.append(self._op(op=OP_CONV, p0=nd.src.act, p1=nd.wf, p2=nd.bias, q0=d.act, q1=pool_dst,
                                     q2=nxt.idx if pool_dst is not None else None, H=d.H,
                                     W=d.W, cin=nd.cin, cout=d.C, taps=9, flags=flags))

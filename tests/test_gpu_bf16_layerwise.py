@@ -62,6 +62,9 @@ def _compare(case: str, what: str, got: torch.Tensor, want: torch.Tensor, *, exa
 @pytest.mark.parametrize("size", [512, 1024])
 def test_bf16_every_stored_tensor_within_one_ulp_of_the_oracle_op(size, monkeypatch):
     monkeypatch.setenv("STV_SYNTHETIC_WEIGHTS", "0")
+    # every tensor the kernels CAN store: the product does not write the pre-pool maps nobody reads again
+    # (STV_POOL_ONLY, plan.py); that form is compared with this one bit for bit at the end of the test
+    monkeypatch.setenv("STV_SKIP_PREPOOL", "0")
     case = f"vgg19_{size}x{size}_bf16 layer-wise"
     content = synthetic.synthetic_image(0, size, size)
     style = synthetic.synthetic_image(1, size, size)
@@ -201,5 +204,30 @@ def test_bf16_every_stored_tensor_within_one_ulp_of_the_oracle_op(size, monkeypa
     record_parity(case, "image gradient from the stored dL/d(conv1_1) (rel rms)", rel, 1e-4,
                   "fp32 output; first-layer weights enter as a two-term bf16 split (2^-16 per product)")
     assert rel <= 1e-4
-    del model, x
+
+    # ------------------------------------------------------------------ the product's default: dead pre-pool maps not stored
+    # Same kernels, same arithmetic, the full-resolution stores of the four pooling convs dropped (conv1_2: 134 of its
+    # 312 MB at 1024^2): every tensor that IS stored, the scores and the image gradient must be bit-identical.
+    monkeypatch.setenv("STV_SKIP_PREPOOL", "1")
+    model2 = core_model.StyleContentModel(S_LAYERS, C_LAYERS, precision="bf16").to(DEV)
+    model2.set_targets(style.to(DEV), content.to(DEV))
+    x2 = x0.to(DEV).requires_grad_(True)
+    scores2 = tuple(float(v) for v in model2.loss_and_grad(x2, STYLE_W, CONTENT_W))
+    torch.cuda.synchronize()
+    eng2 = next(iter(model2._engines.values()))
+    skipped = [nd for nd in eng2.sched.nodes if not nd.dst.stored]
+    assert len(skipped) == 4 and all(nd.kind == "conv" for nd in skipped), [nd.layer for nd in skipped]
+    assert scores2 == (s_hip, c_hip, t_hip)
+    assert torch.equal(x2.grad, x.grad)
+    for nd, nd2 in zip(nodes, eng2.sched.nodes, strict=True):
+        if nd2.dst.stored:
+            assert torch.equal(nd.dst.act, nd2.dst.act), f"L{nd.layer:02d} {nd.kind}: stored activation differs"
+        if nd.idx is not None:
+            assert torch.equal(nd.idx, nd2.idx), f"L{nd.layer:02d}: arg-max map differs"
+        if nd2.dst.grad is not None and not (routed and nd.kind == "pool"):
+            assert torch.equal(nd.dst.grad, nd2.dst.grad), f"L{nd.layer:02d} {nd.kind}: stored gradient differs"
+    skipped_mb = sum(nd.dst.act.numel() * 2 for nd in skipped) / 1e6
+    record_parity(case, "pre-pool maps not stored (STV_POOL_ONLY): everything else vs the all-stored run", 0.0, 0.0,
+                  f"bit-identical scores, image gradient, {len(nodes) - 4} activations, arg-max maps, gradients; {skipped_mb:.0f} MB of stores dropped per closure")
+    del model, x, model2, x2
     torch.cuda.empty_cache()

@@ -159,6 +159,8 @@ def test_fullsize_closure_and_lbfgs_steps_match_oracle(size, precision, monkeypa
         record_parity(case, f"{tag} grad vs fp64 on the same branch (rel rms)", err_hip, bound,
                       note + f"{flips} ReLU/pool decisions differ between the two fp32 paths")
         assert err_hip <= bound, f"{case} {tag}: HIP {err_hip:.2e} on its own branch vs float64 (bound {bound:.1e})"
+        if not cpu_branch:
+            return                      # (the per-pixel fp32-vs-fp32 row below: at 512^2 only, 8 s of host time at 1024^2)
         g32_h = ocm.loss_and_grad(pu.lock(oracle, dec_hip), xc, STYLE_W, CONTENT_W)[3]
         mx = float((g - g32_h).abs().max() / g32_h.abs().max())
         record_parity(case, f"{tag} grad HIP vs CPU-fp32 given the HIP decisions, per pixel max (of scale)", mx, 1e-3)
