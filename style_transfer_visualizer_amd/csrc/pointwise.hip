@@ -228,14 +228,31 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const T* __restrict__ x, 
 }
 
 // ----------------------------------------------------------------- content
+// One partial sum per workgroup, STV_CONTENT_LOSS_PARTS workgroups (the caller's buffer has that many entries; they are
+// added in index order by loss_combine).  Workgroups of 1,024 threads: 256 x 256 threads walking 25-50 MB were four waves
+// per CU with one 16-byte load pair in flight each - 3.2 TB/s (15.7 us for 50 MB at 1024^2); sixteen waves per CU
+// stream.  Per-thread sums are added wave by wave in fixed order: deterministic.
+constexpr int kContentThreads = 1024;
+__device__ __forceinline__ float block_sum_1024(float v, float* smem16) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) smem16[w] = v;
+  __syncthreads();
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < kContentThreads / 64; ++i) s += smem16[i];
+  return s;
+}
 template <typename T>
-__global__ __launch_bounds__(256) void content_loss_kernel(const T* __restrict__ f, const T* __restrict__ t,
-                                                           float* __restrict__ part, size_t n) {
+__global__ __launch_bounds__(kContentThreads) void content_loss_kernel(const T* __restrict__ f, const T* __restrict__ t,
+                                                                       float* __restrict__ part, size_t n) {
   constexpr int kVec = elem_traits<T>::kVec;
-  __shared__ float red[4];
+  constexpr int BT = kContentThreads;
+  __shared__ float red[BT / 64];
   float s = 0.0f;
   const size_t nv = n / kVec;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
+  for (size_t i = (size_t)blockIdx.x * BT + threadIdx.x; i < nv; i += (size_t)gridDim.x * BT) {
     float a[kVec], b[kVec];
     unpack16<T>(reinterpret_cast<const u32x4*>(f)[i], a);
     unpack16<T>(reinterpret_cast<const u32x4*>(t)[i], b);
@@ -245,26 +262,27 @@ __global__ __launch_bounds__(256) void content_loss_kernel(const T* __restrict__
       s = fmaf(d, d, s);
     }
   }
-  for (size_t i = nv * kVec + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+  for (size_t i = nv * kVec + (size_t)blockIdx.x * BT + threadIdx.x; i < n; i += (size_t)gridDim.x * BT) {
     const float d = elem_traits<T>::load(f + i) - elem_traits<T>::load(t + i);
     s = fmaf(d, d, s);
   }
-  s = block_sum_256(s, red);
+  s = block_sum_1024(s, red);
   if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
 // Loss and gradient of the content term in one pass over (F, target): the same partial sums in the same
 // order as content_loss_kernel (same grid, same stride), and dF = coef * 2/n * (F - target) WRITTEN (the dgrad
 // that produces this layer's gradient later accumulates onto it) - one read of the two maps instead of two.
 template <typename T>
-__global__ __launch_bounds__(256) void content_loss_grad_kernel(const T* __restrict__ f, const T* __restrict__ t,
-                                                                float* __restrict__ part, T* __restrict__ df, size_t n,
-                                                                float coef) {
+__global__ __launch_bounds__(kContentThreads) void content_loss_grad_kernel(const T* __restrict__ f, const T* __restrict__ t,
+                                                                            float* __restrict__ part, T* __restrict__ df, size_t n,
+                                                                            float coef) {
   constexpr int kVec = elem_traits<T>::kVec;
-  __shared__ float red[4];
+  constexpr int BT = kContentThreads;
+  __shared__ float red[BT / 64];
   const float k = coef * (2.0f / (float)n);
   float s = 0.0f;
   const size_t nv = n / kVec;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
+  for (size_t i = (size_t)blockIdx.x * BT + threadIdx.x; i < nv; i += (size_t)gridDim.x * BT) {
     float a[kVec], b[kVec], o[kVec];
     unpack16<T>(reinterpret_cast<const u32x4*>(f)[i], a);
     unpack16<T>(reinterpret_cast<const u32x4*>(t)[i], b);
@@ -276,12 +294,12 @@ __global__ __launch_bounds__(256) void content_loss_grad_kernel(const T* __restr
     }
     reinterpret_cast<u32x4*>(df)[i] = pack16<T>(o);
   }
-  for (size_t i = nv * kVec + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+  for (size_t i = nv * kVec + (size_t)blockIdx.x * BT + threadIdx.x; i < n; i += (size_t)gridDim.x * BT) {
     const float d = elem_traits<T>::load(f + i) - elem_traits<T>::load(t + i);
     s = fmaf(d, d, s);
     elem_traits<T>::store(df + i, k * d);
   }
-  s = block_sum_256(s, red);
+  s = block_sum_1024(s, red);
   if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
 template <typename T>
@@ -536,10 +554,10 @@ extern "C" int stv_content_loss(const void* F, const void* target, float* loss_p
   if (!F || !target || !loss_part || n == 0) return STV_ERR_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dtype == STV_F32)
-    hipLaunchKernelGGL(content_loss_kernel<float>, dim3(STV_CONTENT_LOSS_PARTS), dim3(256), 0, st,
+    hipLaunchKernelGGL(content_loss_kernel<float>, dim3(STV_CONTENT_LOSS_PARTS), dim3(kContentThreads), 0, st,
                        static_cast<const float*>(F), static_cast<const float*>(target), loss_part, n);
   else if (dtype == STV_BF16)
-    hipLaunchKernelGGL(content_loss_kernel<bf16_t>, dim3(STV_CONTENT_LOSS_PARTS), dim3(256), 0, st,
+    hipLaunchKernelGGL(content_loss_kernel<bf16_t>, dim3(STV_CONTENT_LOSS_PARTS), dim3(kContentThreads), 0, st,
                        static_cast<const bf16_t*>(F), static_cast<const bf16_t*>(target), loss_part, n);
   else
     return STV_ERR_ARG;
@@ -551,10 +569,10 @@ extern "C" int stv_content_loss_grad(const void* F, const void* target, float* l
   if (!F || !target || !loss_part || !dF || n == 0) return STV_ERR_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dtype == STV_F32)
-    hipLaunchKernelGGL(content_loss_grad_kernel<float>, dim3(STV_CONTENT_LOSS_PARTS), dim3(256), 0, st,
+    hipLaunchKernelGGL(content_loss_grad_kernel<float>, dim3(STV_CONTENT_LOSS_PARTS), dim3(kContentThreads), 0, st,
                        static_cast<const float*>(F), static_cast<const float*>(target), loss_part, static_cast<float*>(dF), n, coef);
   else if (dtype == STV_BF16)
-    hipLaunchKernelGGL(content_loss_grad_kernel<bf16_t>, dim3(STV_CONTENT_LOSS_PARTS), dim3(256), 0, st,
+    hipLaunchKernelGGL(content_loss_grad_kernel<bf16_t>, dim3(STV_CONTENT_LOSS_PARTS), dim3(kContentThreads), 0, st,
                        static_cast<const bf16_t*>(F), static_cast<const bf16_t*>(target), loss_part, static_cast<bf16_t*>(dF), n, coef);
   else
     return STV_ERR_ARG;
