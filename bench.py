@@ -59,8 +59,9 @@ def conv_flops(meta) -> float:
 _CFG_NAMES = {0: "8, 128, 4, 2", 1: "8, 64, 4, 2", 2: "4, 128, 1, 4", 3: "4, 64, 2, 2", 4: "4, 64, 2, 2", 5: "8, 64, 4, 2", 6: "4, 64, 2, 2", 7: "2, 64, 2, 2", 8: "1, 64, 1, 2",
               9: "16, 64, 4, 2", 10: "16, 64, 4, 2", 11: "2, 32, 2, 1", 12: "4, 32, 4, 1",
               13: "8, 64, 4, 2", 14: "16, 64, 4, 2", 15: "4, 64, 2, 2", 16: "2, 32, 2, 1", 17: "4, 32, 4, 1"}
-_CFG_KS = {0: "1, 3", 1: "1, 3", 2: "1, 3", 3: "1, 3", 4: "2, 3", 5: "1, 2", 6: "1, 2", 7: "2, 3", 8: "2, 3", 9: "1, 3", 10: "1, 2",
-           11: "2, 3", 12: "2, 3", 13: "1, 4, true", 14: "1, 4, true", 15: "1, 4, true", 16: "2, 4, true", 17: "2, 4, true"}      # (tests/test_abi.py keeps these two tables as long as the library's list of tiles)
+_CFG_KS = {0: "1, 3, false", 1: "1, 3, false", 2: "1, 3, false", 3: "1, 3, false", 4: "2, 3, false", 5: "1, 2, false", 6: "1, 2, false", 7: "2, 3, false",
+           8: "2, 3, false", 9: "1, 3, false", 10: "1, 2, false", 11: "2, 3, false", 12: "2, 3, false",
+           13: "1, 4, true", 14: "1, 4, true", 15: "1, 4, true", 16: "2, 4, true", 17: "2, 4, true"}      # (tests/test_abi.py keeps these two tables as long as the library's list of tiles)
 
 
 def kernel_group(meta, OP, dtype_code: int = 1, flags: int = 0) -> str | None:
@@ -69,7 +70,7 @@ def kernel_group(meta, OP, dtype_code: int = 1, flags: int = 0) -> str | None:
     op, H, W, cin, cout, taps, _n = meta
     if op == OP["CONV"]:
         if taps == 9 and _lib.load().stv_conv_uses_ws(H, W, cin, cout, taps, dtype_code, 0, 1 if _n > 0 else 0, 0):
-            return f"conv_ws_kernel<{'true' if _n > 0 else 'false'}>"      # weight-stationary persistent kernel (Cin = 64)
+            return f"conv_ws_kernel<{cin}, {'true' if _n > 0 else 'false'}>"      # weight-stationary persistent kernel (Cin = 64 / 128; DG)
         # (a dgrad with the pooling backward in its epilogue has its own tune-table entry: stv.h STV_TUNE_ROUTE)
         cfg = _lib.load().stv_conv_config(H, W, cin, cout, 109 if (flags & _lib.POOL_ROUTE) else taps, dtype_code)
         elem = "unsigned short" if dtype_code == 1 else "float"
@@ -99,9 +100,12 @@ def pmc_traffic(kernel: str, size: int) -> tuple[int | None, str | None]:
     path = found[-1]
 
     def key(name: str) -> str:
-        m = re.search(r"(\w+_kernel|\w+_c64)\W.*?((?:unsigned short|float)?[\d, ]*\d)\s*>", name)
+        if "conv_ws_kernel" in name:                                         # conv_ws_kernel<CIN, DG, ...>: keyed by Cin and the backward flag
+            mw = re.search(r"(conv_ws_kernel<\d+,\s*\w+)", name)
+            return re.sub(r"\s+", "", mw.group(1)) if mw else re.sub(r"\s+", "", name)
+        m = re.search(r"(\w+_kernel|\w+_c64)\W.*?((?:unsigned short|float)?[\d, ]*\d(?:,\s*(?:true|false))?)\s*>", name)
         if m is None:
-            m2 = re.search(r"(conv_ws_kernel<\w+)", name)       # conv_ws_kernel<DG, RELU_IN>: keyed by its first flag
+            m2 = re.search(r"(conv_ws_kernel<\d+,\s*\w+)", name)       # conv_ws_kernel<CIN, DG, ...>: keyed by Cin and the backward flag
             return re.sub(r"\s+", "", m2.group(1)) if m2 else re.sub(r"\s+", "", name)
         inst = re.search(r">\s*,\s*(true|false)\s*>", name)                # conv_igemm_kernel<Cfg<...>, RELU>
         return re.sub(r"\s+", "", m.group(1) + "|" + m.group(2) + ("|" + inst.group(1) if inst else ""))

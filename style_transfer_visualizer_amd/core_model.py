@@ -319,14 +319,23 @@ class _Engine:
         if len(deferred) < 2 or len(deferred) > 8 or not x.is_cuda:
             deferred = []
         held = {id(tap) for tap in deferred}
+        # Round 4: a LARGE tap keeps only its partial-sum pass behind its producer (that pass reads the activation:
+        # 67-134 MB at 1024^2); its FINISH pass - a reduction of a few MB of fp32 slabs - joins the batched finish
+        # launch at the end of the forward pass instead of being a 6-7 us launch of its own (two launches fewer at
+        # 1024^2; STV_GRAM_FIN_LATE=0: finish right behind the partial sums, as before).  Same kernels' bodies, same
+        # summation order: bit-identical results.
+        late: list = []
+        fin_late = bool(deferred) and os.environ.get("STV_GRAM_FIN_LATE", "1") != "0" and len(s.style_taps) <= 8
 
         def batched_tail() -> list:
             # built AFTER the forward ops: whether the first layer leaves its own Gram slabs
             # (tap.partials_fused) is decided while those are emitted
             if not deferred:
                 return []
+            members = sorted(deferred + late, key=lambda t: t.order)
             specs = [dict(tap=tap, target=tap.target, loss_part=self.parts[tap.parts_off:],
-                          sgrad=tap.sgrad if with_seed else None, coef=style_coef) for tap in deferred]
+                          sgrad=tap.sgrad if with_seed else None, coef=style_coef,
+                          partials_ready=any(tap is t for t in late)) for tap in members]
             return [s.gram_multi_op(specs)]
         if deferred and len(deferred) == len(s.style_taps):
             fwd = s.forward_ops(x)
@@ -339,9 +348,16 @@ class _Engine:
         def after(node):
             out = []
             for tap in node.dst.taps:
-                if id(tap) not in held:
-                    out += self._tap_loss_ops(tap, style_coef=style_coef, coef_dev=None, with_seed=with_seed,
-                                              content_coef=content_coef)
+                if id(tap) in held:
+                    continue
+                if fin_late and tap.kind == "style":
+                    if not tap.partials_fused:      # (a first layer that left its own slabs has nothing to do here)
+                        out += s.gram_ops(tap, gram_out=None, target=None, loss_part=None, sgrad=None, coef=0.0,
+                                          coef_dev=None, finish=False)
+                    late.append(tap)
+                    continue
+                out += self._tap_loss_ops(tap, style_coef=style_coef, coef_dev=None, with_seed=with_seed,
+                                          content_coef=content_coef)
             return out
         if os.environ.get("STV_LOSS_INTERLEAVE", "1") == "1":
             fwd = self.sched.forward_ops(x, after_node=after)

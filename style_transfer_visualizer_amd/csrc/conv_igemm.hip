@@ -356,7 +356,7 @@ extern "C" int stv_conv_uses_ws(int H, int W, int cin, int cout, int taps, int d
   static const char dummy = 0;
   ConvArgs a{&dummy, &dummy, nullptr, has_ref ? &dummy : nullptr, const_cast<char*>(&dummy), H, W, cin, cout, flags,
              has_pool ? const_cast<char*>(&dummy) : nullptr, nullptr, has_ref ? &dummy : nullptr, has_ref ? &dummy : nullptr,
-             has_ref ? 64 : 0};
+             has_ref ? cout : 0};      // (cin2 = the layer's own channel count: the Gram term of its tap)
   return stv_conv_ws_supported(a, dtype, taps) ? 1 : 0;
 }
 

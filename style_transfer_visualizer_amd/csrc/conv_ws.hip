@@ -23,6 +23,13 @@
 //
 // Fragment layouts, swizzle and accumulator layout are those of conv_igemm.hip: MFMA rows = output
 // channels, columns = pixels; a lane of an accumulator holds 16 channels (4 groups of 4) of one pixel.
+//
+// Round 4: the kernel is a template on Cin.  Cin = 128 (conv2_2 and its backward, 128 -> 128): the four waves sit
+// side by side along the output channels (32 each = all 128 of the layer: the input is staged once, not once per
+// channel block), a wave keeps 8 stages x 9 taps = 72 fragments = 288 weight registers, and the tile shrinks to
+// 2 rows x 32 pixels so that accumulators, three A column sets and the packed epilogue words still fit the 512
+// registers of a lone wave (DESIGN.md 3.7 worked the budget out); the whole-K halo tile is 4 x 34 pixels x 256 B =
+// 40 KB (three buffers forward, two + the 16-KB z tile backward).
 #include <stdlib.h>
 
 #include <mutex>
@@ -33,29 +40,48 @@
 #ifndef STV_STORE_AUX
 #define STV_STORE_AUX 0      // cache-policy bits of the output stores (diagnostic builds: 2 = nt, 16 = sc1)
 #endif
+#ifndef STV_WS128_DEFAULT
+#define STV_WS128_DEFAULT 1  // the 128 -> 128 layer on this kernel unless STV_CONV_WS128=0
+#endif
 
 namespace {
 
-constexpr int TH = 8, TW = 32;                     // workgroup tile: 8 rows x 32 pixels
-constexpr int MT = 4;                              // rows per wave (two waves along M, two along N)
-constexpr int IN_H = TH + 2, IN_W = TW + 2, IN_PIX = IN_H * IN_W;   // 10 x 34 halo tile
-constexpr int KB = 32, CK = 16, NSTAGE = 4;        // Cin = 64 = four K-stages of 16 channels (32 bytes)
-constexpr int IN_PIECES = (IN_PIX * 2 + 63) / 64;  // 1-KiB DMA pieces per stage (64 slots of 16 B)
-constexpr int IN_STAGE = IN_PIECES * 1024;
-constexpr int IN_BYTES = NSTAGE * IN_STAGE;        // 45,056
-constexpr int F_PIX = TH * TW;
-constexpr int F_PIECES = F_PIX * 2 / 64;           // 8
-constexpr int F_STAGE = F_PIECES * 1024;
-constexpr int F_BYTES = NSTAGE * F_STAGE;          // 32,768
-constexpr int AROWS = MT + 2;
+constexpr int TW = 32, IN_W = TW + 2;
+constexpr int KB = 32, CK = 16;                    // a K-stage = 16 channels = 32 bytes per pixel
 constexpr uint32_t kOob = 0x80000000u;             // >= num_records of every tensor accepted here
+
+// Geometry by input channel count.  64: 2 x 2 waves (rows x channel halves), 8-row tiles, 64 output channels per
+// workgroup.  128: 1 x 4 waves, 2-row tiles, 128 output channels per workgroup.
+template <int CIN> struct WsGeom {
+  static_assert(CIN == 64 || CIN == 128, "weight-stationary kernel: Cin 64 or 128");
+  static constexpr int NSTAGE = CIN / CK;                    // K-stages of 16 channels
+  static constexpr int WN = CIN == 64 ? 2 : 4, WM = 4 / WN;   // waves along output channels / along rows
+  static constexpr int TH = CIN == 64 ? 8 : 2;               // tile rows
+  static constexpr int MT = TH / WM;                         // rows per wave: 4 / 2
+  static constexpr int COUT = 32 * WN;                       // output channels per workgroup
+  static constexpr int IN_H = TH + 2, IN_PIX = IN_H * IN_W;  // halo tile
+  static constexpr int IN_PIECES = (IN_PIX * 2 + 63) / 64;   // 1-KiB DMA pieces per stage (64 slots of 16 B)
+  static constexpr int IN_STAGE = IN_PIECES * 1024;
+  static constexpr int IN_BYTES = NSTAGE * IN_STAGE;         // 45,056 / 40,960
+  static constexpr int F_PIX = TH * TW;
+  static constexpr int F_PIECES = F_PIX * 2 / 64;            // = TH: one piece per tile row
+  static constexpr int F_STAGE = F_PIECES * 1024;
+  static constexpr int FSTAGES = COUT / CK;                  // the z tile has the layer's output channels
+  static constexpr int F_BYTES = FSTAGES * F_STAGE;          // 32,768 / 16,384
+  static constexpr int AROWS = MT + 2;
+  static constexpr int NCOL = 3 * NSTAGE;                    // tap columns of a tile: (stage, dx)
+  static constexpr int NCHUNK = 3 * MT;                      // deferred epilogue chunks: MT row stores + 2 MT pooling half-steps
+  static constexpr int SPW = NSTAGE / 4;                     // K-stages each wave fetches per tile
+  static_assert(NCHUNK <= NCOL, "one epilogue chunk per tap column");
+};
 
 // tile buffers in LDS: the backward form (halo tile + z tile) fits two, the forward form three - the halo
 // tile then streams in two tiles ahead of its use
-template <bool DG> struct WsLds {
-  static constexpr int BUF = IN_BYTES + (DG ? F_BYTES : 0), NB = DG ? 2 : 3, BYTES = NB * BUF;
+template <int CIN, bool DG> struct WsLds {
+  static constexpr int BUF = WsGeom<CIN>::IN_BYTES + (DG ? WsGeom<CIN>::F_BYTES : 0), NB = DG ? 2 : 3, BYTES = NB * BUF;
 };
-static_assert(WsLds<true>::BYTES <= 160 * 1024, "LDS budget");
+static_assert(WsLds<64, true>::BYTES <= 160 * 1024 && WsLds<64, false>::BYTES <= 160 * 1024, "LDS budget");
+static_assert(WsLds<128, true>::BYTES <= 160 * 1024 && WsLds<128, false>::BYTES <= 160 * 1024, "LDS budget");
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -68,54 +94,58 @@ __device__ __forceinline__ bf16x8v relu_frag(bf16x8v v, uint32_t floor) {
   return __builtin_bit_cast(bf16x8v, __builtin_elementwise_max(__builtin_bit_cast(s16x8, v), lo));
 }
 
-template <bool DG, bool RELU_IN, bool POOL, bool MASKED = false, bool DUAL = false>
+template <int CIN, bool DG, bool RELU_IN, bool POOL, bool MASKED = false, bool DUAL = false>
 __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgroups, int diag) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using lds_ptr = __attribute__((address_space(3))) void*;
+  using G = WsGeom<CIN>;
+  constexpr int NSTAGE = G::NSTAGE, TH = G::TH, MT = G::MT, IN_PIX = G::IN_PIX, IN_PIECES = G::IN_PIECES, IN_STAGE = G::IN_STAGE,
+                IN_BYTES = G::IN_BYTES, F_PIECES = G::F_PIECES, F_STAGE = G::F_STAGE, FSTAGES = G::FSTAGES, AROWS = G::AROWS,
+                NCOL = G::NCOL, NCHUNK = G::NCHUNK, COUT = G::COUT, PIX_BYTES = CIN * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 3;     // scalar; also the K-stage this wave fetches
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 3;     // scalar; also the first K-stage this wave fetches
+  const int wm = wave / G::WN, wn = wave % G::WN;
   const int r = lane & 31, h = lane >> 5;
 
   // persistent mapping: this workgroup owns one 64-channel output block and every `tstride`-th tile
   const int tiles_x = (a.W + TW - 1) / TW;
   const int ntiles = tiles_x * ((a.H + TH - 1) / TH);
-  const int ncb = a.cout / 64;
+  const int ncb = a.cout / COUT;
   const int cb = (int)blockIdx.x % ncb;
   const int t_first = (int)blockIdx.x / ncb, tstride = n_workgroups / ncb;
-  const int n0 = cb * 64;
+  const int n0 = cb * COUT;
   const int nb = n0 + wn * 32;                                       // first output channel of this wave
 
   const bf16_t* __restrict__ xin = static_cast<const bf16_t*>(a.x);
   const bool w_blocked = (a.flags & STV_W_BLOCKED) != 0;
-  const int x_bytes = a.H * a.W * 64 * 2;
+  const int x_bytes = a.H * a.W * PIX_BYTES;
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(xin), 0, x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_f = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<void*>(DG ? a.ref : nullptr), 0, DG ? a.H * a.W * 64 * 2 : 0, 0x00020000);
+      const_cast<void*>(DG ? a.ref : nullptr), 0, DG ? a.H * a.W * COUT * 2 : 0, 0x00020000);
 
-  // ---- resident weights: 4 stages x 9 taps, one 16-byte fragment each (row = channel nb + r, k = 8h..8h+7)
+  // ---- resident weights: NSTAGE stages x 9 taps, one 16-byte fragment each (row = channel nb + r, k = 8h..8h+7)
   bf16x8v wreg[NSTAGE][9];
   {
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, 9 * a.cout * 64 * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, 9 * a.cout * CIN * 2, 0x00020000);
 #pragma unroll
     for (int s = 0; s < NSTAGE; ++s)
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const int n = nb + r;
-        const int elem = w_blocked ? (((tap * NSTAGE + s) * a.cout + n) * CK + h * 8) : ((tap * a.cout + n) * 64 + s * CK + h * 8);
+        const int elem = w_blocked ? (((tap * NSTAGE + s) * a.cout + n) * CK + h * 8) : ((tap * a.cout + n) * CIN + s * CK + h * 8);
         wreg[s][tap] = __builtin_bit_cast(bf16x8v, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (uint32_t)(elem * 2), 0, 0));
       }
   }
-  bf16x8v sreg[NSTAGE];          // DG with a fused 1x1 term: S rows of this wave's channels (plain [cout][64])
+  bf16x8v sreg[DG && DUAL ? FSTAGES : 1];          // DG with a fused 1x1 term: S rows of this wave's channels (plain [cout][cout])
   constexpr bool dual = DG && DUAL;                // (compile-time, like POOL: no branch between MFMA groups)
-  if (DG) {
-    const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w2), 0, dual ? 64 * 64 * 2 : 0, 0x00020000);
+  if constexpr (dual) {
+    const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w2), 0, COUT * COUT * 2, 0x00020000);
 #pragma unroll
-    for (int s = 0; s < NSTAGE; ++s)
-      sreg[s] = __builtin_bit_cast(bf16x8v, __builtin_amdgcn_raw_buffer_load_b128(rs_s, (uint32_t)((((nb - n0) + r) * 64 + s * CK + h * 8) * 2), 0, 0));
+    for (int s = 0; s < FSTAGES; ++s)
+      sreg[s] = __builtin_bit_cast(bf16x8v, __builtin_amdgcn_raw_buffer_load_b128(rs_s, (uint32_t)((((nb - n0) + r) * COUT + s * CK + h * 8) * 2), 0, 0));
   }
   const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, a.bias != nullptr ? a.cout * 4 : 0, 0x00020000);
   f32x4 bias_v[4];
@@ -126,8 +156,8 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgrou
     for (int e = 0; e < 4; ++e) bias_v[j][e] = __uint_as_float(t[e]);
   }
 
-  // ---- DMA bookkeeping.  Wave w fetches K-stage w of a tile: IN_PIECES pieces of the halo tile (and
-  // F_PIECES of the centre tile of z).  Slot v = piece * 64 + lane holds half (v & 1) ^ swizzle of pixel
+  // ---- DMA bookkeeping.  Wave w fetches the K-stages w, w + 4, ... of a tile: IN_PIECES pieces of the halo tile
+  // each (and F_PIECES of the centre tile of z per stage of z).  Slot v = piece * 64 + lane holds half (v & 1) ^ swizzle of pixel
   // v >> 1; its source offset is tile_base + rel, with rel a per-lane constant of the kernel.
   int in_rel[IN_PIECES], in_yx[IN_PIECES];
 #pragma unroll
@@ -135,7 +165,7 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgrou
     const int pix = p * 32 + (lane >> 1);
     const int half = (lane & 1) ^ ((pix >> 3) & 1);
     const int py = pix / IN_W, px = pix - py * IN_W;
-    in_rel[p] = (py * a.W + px) * 128 + half * 16;
+    in_rel[p] = (py * a.W + px) * PIX_BYTES + half * 16;
     in_yx[p] = pix < IN_PIX ? ((py << 8) | px) : (0x3FFF << 8);      // slots past the tile: never in range
   }
   const int f_half = (lane & 1) ^ (((lane >> 1) >> 3) & 1);           // pixel = p * 32 + (lane >> 1): bit 3 is the lane's
@@ -143,26 +173,36 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgrou
   auto issue_tile = [&](int t, char* buf) {
     const int ty = t / tiles_x, tx = t - ty * tiles_x;
     const int y0 = ty * TH, x0 = tx * TW;
-    const int base = ((y0 - 1) * a.W + (x0 - 1)) * 128;
-    char* dst = buf + wave * IN_STAGE;
+    const int base = ((y0 - 1) * a.W + (x0 - 1)) * PIX_BYTES;
 #pragma unroll
-    for (int p = 0; p < IN_PIECES; ++p) {
-      const int gy = y0 - 1 + (in_yx[p] >> 8), gx = x0 - 1 + (in_yx[p] & 255);
-      const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-      const uint32_t off = ok ? (uint32_t)(base + in_rel[p]) : kOob;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr)(dst + p * 1024), 16, off, wave * KB, 0, 0);
+    for (int sw = 0; sw < G::SPW; ++sw) {
+      const int stage = wave + 4 * sw;
+      char* dst = buf + stage * IN_STAGE;
+#pragma unroll
+      for (int p = 0; p < IN_PIECES; ++p) {
+        const int gy = y0 - 1 + (in_yx[p] >> 8), gx = x0 - 1 + (in_yx[p] & 255);
+        const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        const uint32_t off = ok ? (uint32_t)(base + in_rel[p]) : kOob;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr)(dst + p * 1024), 16, off, stage * KB, 0, 0);
+      }
     }
     if (DG) {
-      char* fdst = buf + IN_BYTES + wave * F_STAGE;
 #pragma unroll
-      for (int p = 0; p < F_PIECES; ++p) {
-        const int gy = y0 + p, gx = x0 + (lane >> 1);
-        const bool ok = gy < a.H && gx < a.W;
-        const uint32_t off = ok ? (uint32_t)((gy * a.W + gx) * 128 + f_half * 16) : kOob;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_f, (lds_ptr)(fdst + p * 1024), 16, off, wave * KB, 0, 0);
+      for (int sw = 0; sw < FSTAGES / 4; ++sw) {
+        const int stage = wave + 4 * sw;
+        char* fdst = buf + IN_BYTES + stage * F_STAGE;
+#pragma unroll
+        for (int p = 0; p < F_PIECES; ++p) {
+          const int gy = y0 + p, gx = x0 + (lane >> 1);
+          const bool ok = gy < a.H && gx < a.W;
+          const uint32_t off = ok ? (uint32_t)((gy * a.W + gx) * (COUT * 2) + f_half * 16) : kOob;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_f, (lds_ptr)(fdst + p * 1024), 16, off, stage * KB, 0, 0);
+        }
       }
     }
   };
+  // vector-memory operations one tile's DMA adds to this wave's queue (the counted wait below)
+  constexpr int kTileOps = G::SPW * IN_PIECES + (DG ? (FSTAGES / 4) * F_PIECES : 0);
 
   // lane-constant LDS offsets of this lane's fragments inside a tile buffer (stage 0)
   int a_addr[3][AROWS];
@@ -182,11 +222,11 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgrou
       a.y, 0, (a.y != nullptr && !(POOL && (a.flags & STV_POOL_ONLY))) ? out_bytes : 0, 0x00020000);
 
   // ---- prologue: first two tiles in flight, weights in registers
-  constexpr int NB = WsLds<DG>::NB;
+  constexpr int NB = WsLds<CIN, DG>::NB;
   int t = t_first;
 #pragma unroll
   for (int b = 0; b < NB; ++b)
-    if (t + b * tstride < ntiles) issue_tile(t + b * tstride, smem + b * WsLds<DG>::BUF);
+    if (t + b * tstride < ntiles) issue_tile(t + b * tstride, smem + b * WsLds<CIN, DG>::BUF);
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
 
@@ -231,6 +271,7 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgrou
   // (No branch on run-time state in here: the chunk has to sit in the same basic block as the MFMAs it
   // hides behind.  Before the first tile `have_prev` is false and every store is aimed out of range.)
   auto deferred = [&](int c) {
+    if (c >= NCHUNK) return;
     if (c < MT) {
       const int gy = py0 + wm * MT + c, gx = px0 + r;
       store_rows(Pp[c], (have_prev && gy < a.H && gx < a.W) ? (uint32_t)(((gy * a.W + gx) * a.cout) * 2) : kOob, rs_y);
@@ -259,7 +300,7 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgrou
       const uint32_t pos = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, m3) + (u16x2)((unsigned short)0x7FFF)) & 0x80008000u;
       codep[mp][q] = (b0 >> 15) | (b1 >> 14) | (pos >> 13);          // per half: a 3-bit code in bits 0-2 / 16-18
     }
-    if (c == MT + 3 || c == MT + 7) {           // all eight words of a window row are done: store it
+    if (((c - MT) & 3) == 3) {                  // all eight words of a window row are done: store it
       const int mp = (c - MT) >> 2;
       const int gyp = ((py0 + wm * MT) >> 1) + mp, gxp = (px0 + r) >> 1;
       const bool pix_ok = have_prev && (r & 1) == 0 && gyp < Hp && gxp < Wp;
@@ -276,7 +317,6 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgrou
       }
     }
   };
-  static_assert(MT == 4 && NSTAGE * 3 == 12, "twelve chunks: four map rows + eight pooling half-steps");
 
   // A fragments: three column sets in flight.  The first two columns of a tile are requested as soon as the tile
   // has landed - for every tile but the first that is right behind the barrier at the end of the previous
@@ -297,7 +337,7 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgrou
   }
   int slot = 0;
   for (; t < ntiles; t += tstride, slot = (slot + 1 == NB) ? 0 : slot + 1) {
-    char* const cur = smem + slot * WsLds<DG>::BUF;
+    char* const cur = smem + slot * WsLds<CIN, DG>::BUF;
     const int ty = t / tiles_x, tx = t - ty * tiles_x;
     const int y0 = ty * TH, x0 = tx * TW;
 
@@ -322,9 +362,9 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgrou
     }
     if (!(diag & 4))
 #pragma unroll
-    for (int col = 0; col < NSTAGE * 3; ++col) {
+    for (int col = 0; col < NCOL; ++col) {
       const int s = col / 3, dx = col - s * 3;
-      if (col + 2 < NSTAGE * 3) load_col(col + 2, (col + 2) % 3);
+      if (col + 2 < NCOL) load_col(col + 2, (col + 2) % 3);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy)
@@ -332,11 +372,11 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgrou
         for (int mt = 0; mt < MT; ++mt)
           acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[s][dy * 3 + dx], af[col % 3][mt + dy],
                                                             (col == 0 && dy == 0) ? acc0 : acc[mt], 0, 0, 0);
-      if (col + 1 < NSTAGE * 3) relu_col((col + 1) % 3);
+      if (col + 1 < NCOL) relu_col((col + 1) % 3);
       if (!DG || col < MT) deferred(col);              // the previous tile's epilogue, one chunk per column
-      if (RELU_IN || !DG || col < MT) {                // 12 MFMAs with the packed max / epilogue VALU in their shadow
+      if (RELU_IN || ((!DG || col < MT) && col < NCHUNK)) {   // 3 MT MFMAs with the packed max / epilogue VALU in their shadow
 #pragma unroll
-        for (int k = 0; k < 12; ++k) {
+        for (int k = 0; k < 3 * MT; ++k) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x002, DG ? 2 : 6, 0);
         }
@@ -363,17 +403,17 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgrou
             acc[mt][4 * j + 3] = ((int)(m.y & 0xFFFF0000u) > 0) ? acc[mt][4 * j + 3] : 0.0f;
           }
         }
-        if (dual) {
+        if constexpr (dual) {
 #pragma unroll
-          for (int s = 0; s < NSTAGE; ++s) {
+          for (int s = 0; s < FSTAGES; ++s) {
             const bf16x8v zf = *reinterpret_cast<const bf16x8v*>(fb + s * F_STAGE + fp * KB + ((h ^ swz) << 4));
             acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sreg[s], zf, acc[mt], 0, 0, 0);
           }
         }
       }
-      // the mask of row mt + 1 (48 VALU) in the shadow of the four 1x1 MFMAs of row mt
+      // the mask of row mt + 1 (48 VALU) in the shadow of the 1x1 MFMAs of row mt
 #pragma unroll
-      for (int k = 0; k < 4 * MT; ++k) {
+      for (int k = 0; k < (dual ? FSTAGES : 0) * MT; ++k) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
       }
@@ -387,14 +427,14 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgrou
     // The previous tile's deferred stores count too: they can only make the wait longer, never satisfied
     // early (the threshold is exactly the newest DMA's size).
     const bool more = t + NB * tstride < ntiles && !(diag & 2);
-    if (NB == 3 && t + 2 * tstride < ntiles && !(diag & 2)) wait_vmcnt<IN_PIECES>();
+    if (NB == 3 && t + 2 * tstride < ntiles && !(diag & 2)) wait_vmcnt<kTileOps>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     if (NB == 2 && more) issue_tile(t + NB * tstride, cur);
 
     if (NB == 3 && more) issue_tile(t + NB * tstride, cur);      // forward form: the stores follow in the next tile's shadow
     if (t + tstride < ntiles) {                                  // the next tile's first two A columns (it has landed)
-      const char* nxt = smem + ((slot + 1 == NB) ? 0 : slot + 1) * WsLds<DG>::BUF;
+      const char* nxt = smem + ((slot + 1 == NB) ? 0 : slot + 1) * WsLds<CIN, DG>::BUF;
       load_col_from(nxt, 0, 0);
       load_col_from(nxt, 1, 1);
     }
@@ -404,7 +444,7 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgrou
     {
       if (diag & 4) {                                  // (timing knock-out without the MFMA loop: nothing carried the chunks)
 #pragma unroll
-        for (int c = 0; c < (DG ? MT : 12); ++c) deferred(c);
+        for (int c = 0; c < (DG ? MT : NCHUNK); ++c) deferred(c);
       }
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
@@ -421,7 +461,7 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgrou
   }
   {                                                    // the last tile's epilogue has no next tile to hide behind
 #pragma unroll
-    for (int c = 0; c < (DG ? MT : 12); ++c) deferred(c);
+    for (int c = 0; c < (DG ? MT : NCHUNK); ++c) deferred(c);
   }
   // every DMA issued was waited for inside the loop (the last two iterations issue none)
 #endif
@@ -440,19 +480,35 @@ int device_cus() {
   return cus[dev];
 }
 
-template <bool DG, bool RELU_IN, bool POOL, bool MASKED = false, bool DUAL = false>
+template <int CIN, bool DG, bool RELU_IN, bool POOL, bool MASKED = false, bool DUAL = false>
 int launch_ws(const ConvArgs& a, hipStream_t st) {
-  if (stv_set_max_lds(reinterpret_cast<const void*>(&conv_ws_kernel<DG, RELU_IN, POOL, MASKED, DUAL>), WsLds<DG>::BYTES) != STV_OK) return STV_ERR_LAUNCH;
-  const int ntiles = ceil_div(a.W, TW) * ceil_div(a.H, TH);
-  const int ncb = a.cout / 64;
+  using G = WsGeom<CIN>;
+  if (stv_set_max_lds(reinterpret_cast<const void*>(&conv_ws_kernel<CIN, DG, RELU_IN, POOL, MASKED, DUAL>), WsLds<CIN, DG>::BYTES) != STV_OK) return STV_ERR_LAUNCH;
+  const int ntiles = ceil_div(a.W, TW) * ceil_div(a.H, G::TH);
+  const int ncb = a.cout / G::COUT;
   int per_cb = device_cus() / ncb;                   // one persistent workgroup per CU
   if (per_cb < 1) per_cb = 1;
   if (per_cb > ntiles) per_cb = ntiles;
   const int n_wg = per_cb * ncb;
   const char* dg = getenv("STV_WS_DIAG");            // timing experiments only (results are then wrong)
-  hipLaunchKernelGGL((conv_ws_kernel<DG, RELU_IN, POOL, MASKED, DUAL>), dim3(n_wg), dim3(256), WsLds<DG>::BYTES, st, a, n_wg, dg ? atoi(dg) : 0);
+  hipLaunchKernelGGL((conv_ws_kernel<CIN, DG, RELU_IN, POOL, MASKED, DUAL>), dim3(n_wg), dim3(256), (WsLds<CIN, DG>::BYTES), st, a, n_wg, dg ? atoi(dg) : 0);
   STV_CHECK_LAUNCH();
   return STV_OK;
+}
+
+template <int CIN>
+int launch_ws_cin(const ConvArgs& a, hipStream_t st) {
+  const bool has_f = (a.flags & STV_MASK) != 0 || a.x2 != nullptr;
+  if (!has_f) {
+    const bool relu = (a.flags & STV_RELU_IN) != 0, pool = a.pool != nullptr;
+    if (relu) return pool ? launch_ws<CIN, false, true, true>(a, st) : launch_ws<CIN, false, true, false>(a, st);
+    return pool ? launch_ws<CIN, false, false, true>(a, st) : launch_ws<CIN, false, false, false>(a, st);
+  }
+  ConvArgs b = a;
+  if (b.ref == nullptr) b.ref = b.x2;              // the z tile is fetched through `ref`
+  const bool masked = (b.flags & STV_MASK) != 0, dual = b.x2 != nullptr;
+  if (masked) return dual ? launch_ws<CIN, true, false, false, true, true>(b, st) : launch_ws<CIN, true, false, false, true, false>(b, st);
+  return launch_ws<CIN, true, false, false, false, true>(b, st);       // has_f without a mask: the 1x1 term is there
 }
 
 }  // namespace
@@ -460,20 +516,28 @@ int launch_ws(const ConvArgs& a, hipStream_t st) {
 bool stv_conv_ws_supported(const ConvArgs& a, int dtype, int taps) {
   // A/B knob; forcing a tile configuration of the general kernel (STV_CONV_CFG) also means: use that kernel
   // STV_CONV_WS: 0 = never, 2 = every supported shape, default (1) = where it measured faster than the
-  // general kernel: the 64 -> 64 layers (conv1_2 forward with its pooling epilogue, and its backward)
+  // general kernel: the 64 -> 64 layers (conv1_2 forward with its pooling epilogue, and its backward) and - round 4,
+  // STV_CONV_WS128 (default from the measurement recorded in DESIGN.md) - the 128 -> 128 layer (conv2_2 and its backward)
   const char* knob = getenv("STV_CONV_WS");
   const int mode = knob ? atoi(knob) : 1;
   if (mode == 0 || getenv("STV_CONV_CFG") != nullptr) return false;
-  if (dtype != STV_BF16 || taps != 9 || a.cin != 64 || a.cout % 64 != 0) return false;
-  if (mode == 1 && a.cout != 64) return false;
+  if (dtype != STV_BF16 || taps != 9 || (a.cin != 64 && a.cin != 128)) return false;
+  const int cout_wg = a.cin == 64 ? 64 : 128;        // output channels of one workgroup (WsGeom::COUT)
+  if (a.cout % cout_wg != 0) return false;
+  if (a.cin == 128) {
+    const char* k128 = getenv("STV_CONV_WS128");
+    if ((k128 ? atoi(k128) : STV_WS128_DEFAULT) == 0 || a.cout != 128) return false;
+  }
+  if (mode == 1 && a.cout != cout_wg) return false;
   if (a.flags & STV_ACCUM) return false;
-  if ((size_t)a.H * a.W * (size_t)(a.cout > 64 ? a.cout : 64) * 2 >= ((size_t)1 << 31)) return false;
+  const size_t cmax = (size_t)(a.cout > a.cin ? a.cout : a.cin);
+  if ((size_t)a.H * a.W * cmax * 2 >= ((size_t)1 << 31)) return false;
   if (a.pool != nullptr && !(a.flags & STV_RELU_OUT)) return false;     // the packed pooling epilogue compares non-negative words
   const bool has_f = (a.flags & STV_MASK) != 0 || a.x2 != nullptr;
   if (has_f) {
-    // the z tile in LDS is 64 channels wide and serves both as ReLU mask and as the 1x1 term's input
-    if (a.cout != 64 || a.pool != nullptr) return false;
-    if (a.x2 != nullptr && (a.cin2 != 64 || a.w2 == nullptr)) return false;
+    // the z tile in LDS is as wide as the workgroup's output channels and serves both as ReLU mask and as the 1x1 term's input
+    if (a.cout != cout_wg || a.pool != nullptr) return false;
+    if (a.x2 != nullptr && (a.cin2 != cout_wg || a.w2 == nullptr)) return false;
     if ((a.flags & STV_MASK) && a.x2 != nullptr && a.ref != a.x2) return false;
     if (a.flags & (STV_RELU_IN | STV_RELU_OUT)) return false;
     if (a.bias != nullptr) return false;
@@ -482,15 +546,5 @@ bool stv_conv_ws_supported(const ConvArgs& a, int dtype, int taps) {
 }
 
 int stv_conv_ws_launch(const ConvArgs& a, hipStream_t st) {
-  const bool has_f = (a.flags & STV_MASK) != 0 || a.x2 != nullptr;
-  if (!has_f) {
-    const bool relu = (a.flags & STV_RELU_IN) != 0, pool = a.pool != nullptr;
-    if (relu) return pool ? launch_ws<false, true, true>(a, st) : launch_ws<false, true, false>(a, st);
-    return pool ? launch_ws<false, false, true>(a, st) : launch_ws<false, false, false>(a, st);
-  }
-  ConvArgs b = a;
-  if (b.ref == nullptr) b.ref = b.x2;              // the z tile is fetched through `ref`
-  const bool masked = (b.flags & STV_MASK) != 0, dual = b.x2 != nullptr;
-  if (masked) return dual ? launch_ws<true, false, false, true, true>(b, st) : launch_ws<true, false, false, true, false>(b, st);
-  return launch_ws<true, false, false, false, true>(b, st);       // has_f without a mask: the 1x1 term is there
+  return a.cin == 64 ? launch_ws_cin<64>(a, st) : launch_ws_cin<128>(a, st);
 }

@@ -14,7 +14,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import ACCUM, MASK, RELU_IN, RELU_OUT, STV_BF16, STV_F32, W_BLOCKED  # noqa: F401
+from ._lib import ACCUM, MASK, POOL_ONLY, RELU_IN, RELU_OUT, STV_BF16, STV_F32, W_BLOCKED  # noqa: F401
 
 
 def dtype_code(dtype: torch.dtype) -> int:

@@ -298,7 +298,7 @@ class Schedule:
 
     def gram_ops(self, tap: Tap, *, gram_out: torch.Tensor | None, target: torch.Tensor | None,
                  loss_part: torch.Tensor | None, sgrad: torch.Tensor | None, coef: float,
-                 coef_dev: torch.Tensor | None, partial: bool = True) -> list[StvOp]:
+                 coef_dev: torch.Tensor | None, partial: bool = True, finish: bool = True) -> list[StvOp]:
         b = tap.buf
         n = b.H * b.W
         if tap.partials is None:
@@ -306,6 +306,8 @@ class Schedule:
         out = []
         if partial and not tap.partials_fused:
             out.append(self._op(op=OP_GRAM_PARTIAL, p0=b.act, q0=tap.partials, n=n, cin=b.C))
+        if not finish:          # (the finish pass runs later, in a batched launch: gram_multi_op with partials_ready)
+            return out
         out.append(self._op(op=OP_GRAM_FINISH, p0=tap.partials, p1=target, p2=coef_dev, q0=gram_out, q1=loss_part,
                             q2=sgrad, n=n, cin=b.C, f0=GRAM_CLAMP_MAX, f1=float(b.C * n), f2=coef))
         return out
@@ -326,7 +328,7 @@ class Schedule:
             n = b.H * b.W
             if tap.partials is None:
                 tap.partials = torch.empty(ops.gram_ksplit(n, b.C), b.C, b.C, device=self.device, dtype=torch.float32)
-            e.F, e.partials = (None if tap.partials_fused else ptr(b.act)), ptr(tap.partials)
+            e.F, e.partials = (None if (tap.partials_fused or sp.get("partials_ready")) else ptr(b.act)), ptr(tap.partials)
             e.target, e.gram_out, e.loss_part = ptr(sp.get("target")), ptr(sp.get("gram_out")), ptr(sp.get("loss_part"))
             e.sgrad, e.coef_dev = ptr(sp.get("sgrad")), ptr(sp.get("coef_dev"))
             e.n_pixels, e.channels = n, b.C

@@ -448,6 +448,36 @@ def test_first_layer_gram_fusion_is_equivalent(monkeypatch):
     assert err < 2e-2
 
 
+def test_late_gram_finish_of_the_large_taps_changes_nothing(monkeypatch):
+    """1024x1024, bf16: conv1_1 (134 MB) and conv2_1 (67 MB) are too large to wait for the batched Gram launch, so
+    their partial-sum passes stay behind their producers - but their FINISH passes (a few MB of fp32 slabs) join the
+    batched finish at the end of the forward pass (round 4).  Against STV_GRAM_FIN_LATE=0 (a finish launch of its own
+    right behind each): two launches fewer, bit-identical scores, seeds and image gradient."""
+    monkeypatch.setenv("STV_SYNTHETIC_WEIGHTS", "0")
+    size = 1024
+    content = synthetic.synthetic_image(0, size, size).to(DEV)
+    style = synthetic.synthetic_image(1, size, size).to(DEV)
+    x0 = torch.randn(1, 3, size, size, generator=torch.Generator().manual_seed(0)).to(DEV)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("STV_GRAM_FIN_LATE", mode)
+        model = core_model.StyleContentModel([0, 5, 10, 19, 28], [21], precision="bf16").to(DEV)
+        model.set_targets(style, content)
+        x = x0.clone().requires_grad_(True)
+        scores = tuple(float(v) for v in model.loss_and_grad(x, 1e5, 1.0))
+        eng = next(iter(model._engines.values()))
+        prog = next(p for k, p in eng._programs.items() if k[0] == "fused")
+        seeds = [t.sgrad.detach().clone() for t in eng.sched.style_taps]
+        out[mode] = (scores, x.grad.detach().clone(), prog.n_ops, seeds, [t.detach().clone() for t in model.style_targets])
+        del model, x
+        torch.cuda.empty_cache()
+    assert out["1"][2] == out["0"][2] - 2, (out["0"][2], out["1"][2])
+    assert out["1"][0] == out["0"][0]
+    assert torch.equal(out["1"][1], out["0"][1])
+    for a, b in zip(out["0"][3] + out["0"][4], out["1"][3] + out["1"][4], strict=True):
+        assert torch.equal(a, b)
+
+
 def test_oracle_agreement_at_larger_size(monkeypatch):
     """Same seeded inputs through oracle (CPU) and HIP at 160x128 with the mini net."""
     case = GoldenCase("mini_white_lbfgs")

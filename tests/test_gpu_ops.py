@@ -230,17 +230,22 @@ def test_conv_igemm_with_fused_maxpool(dtype, cfg, case, monkeypatch):
         assert torch.equal(a, b2), f"idx backward differs, flags={flags}"
 
 
-@pytest.mark.parametrize("case", [(64, 75, 101), (128, 40, 72), (64, 8, 32), (64, 13, 7), (64, 512, 512), (128, 256, 320)])
+@pytest.mark.parametrize("case", [(64, 64, 75, 101), (64, 128, 40, 72), (64, 64, 8, 32), (64, 64, 13, 7), (64, 64, 512, 512), (64, 128, 256, 320),
+                                  (128, 128, 75, 101), (128, 128, 2, 32), (128, 128, 13, 7), (128, 128, 3, 40), (128, 128, 256, 320),
+                                  (128, 128, 512, 512)])
 def test_conv_ws_forward_pool_and_backward(case, monkeypatch):
-    """The weight-stationary persistent kernel (csrc/conv_ws.hip; bf16, Cin = 64): forward with bias /
-    ReLU-on-load / ReLU / fused max-pool + arg-max map, and the backward form mask(z>0)*dgrad + z.S^T,
-    on ragged images, on single-tile images and on images with several tiles per workgroup."""
-    cout, H, W = case
+    """The weight-stationary persistent kernel (csrc/conv_ws.hip; bf16; Cin = 64: 8 x 32-pixel tiles, 2 x 2 waves;
+    Cin = 128, 128 -> 128: 2 x 32-pixel tiles, four waves along the output channels): forward with bias /
+    ReLU-on-load / ReLU / fused max-pool + arg-max map (also without the full-resolution store: STV_POOL_ONLY), and
+    the backward form mask(z>0)*dgrad + z.S^T, on ragged images, on single-tile images and on images with several
+    tiles per workgroup."""
+    cin, cout, H, W = case
     dtype = torch.bfloat16
     monkeypatch.setenv("STV_CONV_WS", "2")          # every supported shape, also those the default leaves to the general kernel
-    assert ops.conv_uses_ws(H, W, 64, cout, dtype, flags=ops.RELU_IN | ops.RELU_OUT | ops.W_BLOCKED)
-    x = rnd((1, 64, H, W), 141)
-    w = rnd((cout, 64, 3, 3), 142, -1, 1) * (2.0 / (9 * 64)) ** 0.5
+    monkeypatch.setenv("STV_CONV_WS128", "1")
+    assert ops.conv_uses_ws(H, W, cin, cout, dtype, flags=ops.RELU_IN | ops.RELU_OUT | ops.W_BLOCKED)
+    x = rnd((1, cin, H, W), 141)
+    w = rnd((cout, cin, 3, 3), 142, -1, 1) * (2.0 / (9 * cin)) ** 0.5
     b = rnd((cout,), 143, -0.2, 0.2)
     xq, wq = q(x, dtype), q(w, dtype)
     for blocked in (True, False):
@@ -251,42 +256,56 @@ def test_conv_ws_forward_pool_and_backward(case, monkeypatch):
             ref = F.conv2d(F.relu(xq) if flags & ops.RELU_IN else xq, wq, b, padding=1)
             ref = F.relu(ref) if flags & ops.RELU_OUT else ref
             y = ops.conv_igemm(ops.to_nhwc(x, dtype).to(DEV), wp, b.to(DEV), flags=flags)
-            assert_close(ops.from_nhwc(y), ref, dtype, 9 * 64, f"ws fwd {case} flags={flags} blocked={blocked}")
+            assert_close(ops.from_nhwc(y), ref, dtype, 9 * cin, f"ws fwd {case} flags={flags} blocked={blocked}")
     # fused pool + arg-max map
     if H >= 2 and W >= 2:
-        assert ops.conv_uses_ws(H, W, 64, cout, dtype, flags=ops.RELU_OUT | ops.W_BLOCKED, has_pool=True)
+        assert ops.conv_uses_ws(H, W, cin, cout, dtype, flags=ops.RELU_OUT | ops.W_BLOCKED, has_pool=True)
         wp = ops.block_weights(ops.pack_weights_fwd(w).to(dtype).to(DEV))
-        idx = torch.full((H // 2, W // 2, cout), 255, device=DEV, dtype=torch.uint8)
-        y, yp = ops.conv_igemm_pool(ops.to_nhwc(x, dtype).to(DEV), wp, b.to(DEV), flags=ops.RELU_OUT, pool_idx=idx)
-        assert_close(ops.from_nhwc(y), F.relu(F.conv2d(xq, wq, b, padding=1)), dtype, 9 * 64, f"ws conv+pool {case}")
-        assert torch.equal(ops.from_nhwc(yp).cpu(), F.max_pool2d(ops.from_nhwc(y).cpu(), 2, 2))
-        assert int(idx.max()) <= 7
+        for relu_in in (0, ops.RELU_IN):
+            idx = torch.full((H // 2, W // 2, cout), 255, device=DEV, dtype=torch.uint8)
+            y, yp = ops.conv_igemm_pool(ops.to_nhwc(x, dtype).to(DEV), wp, b.to(DEV), flags=ops.RELU_OUT | relu_in, pool_idx=idx)
+            ref = F.relu(F.conv2d(F.relu(xq) if relu_in else xq, wq, b, padding=1))
+            assert_close(ops.from_nhwc(y), ref, dtype, 9 * cin, f"ws conv+pool {case} relu_in={relu_in}")
+            assert torch.equal(ops.from_nhwc(yp).cpu(), F.max_pool2d(ops.from_nhwc(y).cpu(), 2, 2))
+            assert int(idx.max()) <= 7
+            # STV_POOL_ONLY: the full map is not written, the pooled map and the arg-max map are the same bits
+            idx2 = torch.full_like(idx, 255)
+            y2 = torch.full_like(y, 7.0)
+            _, yp2 = ops.conv_igemm_pool(ops.to_nhwc(x, dtype).to(DEV), wp, b.to(DEV), flags=ops.RELU_OUT | relu_in | ops.POOL_ONLY,
+                                         out=y2, pool_idx=idx2)
+            assert torch.equal(yp2, yp) and torch.equal(idx2, idx) and bool((y2 == 7.0).all())
         dyp = ops.to_nhwc(rnd((1, cout, H // 2, W // 2), 144), dtype).to(DEV)
         for flags in (0, ops.MASK):
             a_, b_ = torch.zeros_like(y), torch.zeros_like(y)
             ops.maxpool_bwd(y, dyp, out=a_, flags=flags)
             ops.maxpool_bwd_idx(idx, dyp, H, W, out=b_, flags=flags)
             assert torch.equal(a_, b_), f"ws arg-max map differs from the activation-based routing, flags={flags}"
-    # backward form (64 -> 64 only): mask and / or the fused Gram term
-    if cout == 64:
-        dy = rnd((1, 64, H, W), 145)
-        z = rnd((1, 64, H, W), 146)
-        s_mat = rnd((64, 64), 147, -0.02, 0.02)
+    # backward form (Cout = Cin only): mask and / or the fused Gram term
+    if cout == cin:
+        dy = rnd((1, cin, H, W), 145)
+        z = rnd((1, cin, H, W), 146)
+        s_mat = rnd((cin, cin), 147, -0.02, 0.02)
         s_mat = (s_mat + s_mat.t()) * 0.5
         dyq, zq, sq = q(dy, dtype), q(z, dtype), q(s_mat, dtype)
-        xr = torch.zeros(1, 64, H, W, requires_grad=True)
+        xr = torch.zeros(1, cin, H, W, requires_grad=True)
         F.conv2d(xr, wq, None, padding=1).backward(dyq)
         wb = ops.block_weights(ops.pack_weights_bwd(w).to(dtype).to(DEV))
         zn = ops.to_nhwc(z, dtype).to(DEV)
         second = torch.einsum("bchw,nc->bnhw", zq, sq)
         for mask in (False, True):
-            assert ops.conv_uses_ws(H, W, 64, 64, dtype, flags=(ops.MASK if mask else 0) | ops.W_BLOCKED, has_ref=True)
+            assert ops.conv_uses_ws(H, W, cin, cin, dtype, flags=(ops.MASK if mask else 0) | ops.W_BLOCKED, has_ref=True)
             first = xr.grad * ((zq > 0).float() if mask else 1.0)
             out = ops.conv_igemm_dual(ops.to_nhwc(dy, dtype).to(DEV), wb, zn, sq.to(dtype).to(DEV).contiguous(),
                                       ref=zn if mask else None, flags=ops.MASK if mask else 0)
-            assert_close(ops.from_nhwc(out), first + second, dtype, 9 * 64 + 64, f"ws dual {case} mask={mask}")
+            assert_close(ops.from_nhwc(out), first + second, dtype, 9 * cin + cin, f"ws dual {case} mask={mask}")
         out = ops.conv_igemm(ops.to_nhwc(dy, dtype).to(DEV), wb, None, ref=zn, flags=ops.MASK)
-        assert_close(ops.from_nhwc(out), xr.grad * (zq > 0).float(), dtype, 9 * 64, f"ws masked dgrad {case}")
+        assert_close(ops.from_nhwc(out), xr.grad * (zq > 0).float(), dtype, 9 * cin, f"ws masked dgrad {case}")
+        # the general kernel on the same launch: the two agree to rounding of a few sums (another summation order)
+        monkeypatch.setenv("STV_CONV_WS", "0")
+        assert not ops.conv_uses_ws(H, W, cin, cin, dtype, flags=ops.MASK | ops.W_BLOCKED, has_ref=True)
+        out_gen = ops.conv_igemm(ops.to_nhwc(dy, dtype).to(DEV), wb, None, ref=zn, flags=ops.MASK)
+        d = (out.float() - out_gen.float()).abs()
+        assert float((d / (2.0 ** -7 * torch.maximum(out.float().abs(), out_gen.float().abs()) + 1e-6)).max()) <= 1.0
 
 
 @pytest.mark.parametrize("cfg", [None, 0, 1, 3, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17])
