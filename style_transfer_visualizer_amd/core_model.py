@@ -323,7 +323,7 @@ class _Engine:
         # 67-134 MB at 1024^2); its FINISH pass - a reduction of a few MB of fp32 slabs - joins the batched finish
         # launch at the end of the forward pass instead of being a 6-7 us launch of its own (two launches fewer at
         # 1024^2; STV_GRAM_FIN_LATE=0: finish right behind the partial sums, as before).  Same kernels' bodies, same
-        # summation order: bit-identical results.
+        # summation order per tap up to the grouping of a many-slab tap's slabs (8 instead of 32 per partial sum).
         late: list = []
         fin_late = bool(deferred) and os.environ.get("STV_GRAM_FIN_LATE", "1") != "0" and len(s.style_taps) <= 8
 

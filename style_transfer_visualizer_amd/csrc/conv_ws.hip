@@ -525,8 +525,17 @@ bool stv_conv_ws_supported(const ConvArgs& a, int dtype, int taps) {
   const int cout_wg = a.cin == 64 ? 64 : 128;        // output channels of one workgroup (WsGeom::COUT)
   if (a.cout % cout_wg != 0) return false;
   if (a.cin == 128) {
+    // STV_CONV_WS128: 0 never, 2 every 128 -> 128 launch, 1 (default) where it measured faster than the general
+    // kernel (round 4, one box, per-op times inside the step): the BACKWARD form (masked dgrad + Gram term) from 8
+    // tiles per workgroup up - 1024^2: 86.5 against 97.8 us; at 512^2 (4 tiles per workgroup) 29.1 against 29.3, and
+    // the forward form is no faster at either size (80.2 against 78.8 us, 27.0 against 23.4): persistence has
+    // little to hide once the general kernel runs two workgroups per CU on this K (8 stages)
     const char* k128 = getenv("STV_CONV_WS128");
-    if ((k128 ? atoi(k128) : STV_WS128_DEFAULT) == 0 || a.cout != 128) return false;
+    const int mode128 = k128 ? atoi(k128) : STV_WS128_DEFAULT;
+    if (mode128 == 0 || a.cout != 128) return false;
+    const bool backward = (a.flags & STV_MASK) != 0 || a.x2 != nullptr;
+    const long tiles = (long)ceil_div(a.W, TW) * ceil_div(a.H, WsGeom<128>::TH);
+    if (mode128 == 1 && !(backward && tiles >= 8L * device_cus())) return false;
   }
   if (mode == 1 && a.cout != cout_wg) return false;
   if (a.flags & STV_ACCUM) return false;

@@ -452,7 +452,7 @@ def test_late_gram_finish_of_the_large_taps_changes_nothing(monkeypatch):
     """1024x1024, bf16: conv1_1 (134 MB) and conv2_1 (67 MB) are too large to wait for the batched Gram launch, so
     their partial-sum passes stay behind their producers - but their FINISH passes (a few MB of fp32 slabs) join the
     batched finish at the end of the forward pass (round 4).  Against STV_GRAM_FIN_LATE=0 (a finish launch of its own
-    right behind each): two launches fewer, bit-identical scores, seeds and image gradient."""
+    right behind each): two launches fewer, the same sums in another fixed order."""
     monkeypatch.setenv("STV_SYNTHETIC_WEIGHTS", "0")
     size = 1024
     content = synthetic.synthetic_image(0, size, size).to(DEV)
@@ -472,10 +472,21 @@ def test_late_gram_finish_of_the_large_taps_changes_nothing(monkeypatch):
         del model, x
         torch.cuda.empty_cache()
     assert out["1"][2] == out["0"][2] - 2, (out["0"][2], out["1"][2])
-    assert out["1"][0] == out["0"][0]
-    assert torch.equal(out["1"][1], out["0"][1])
-    for a, b in zip(out["0"][3] + out["0"][4], out["1"][3] + out["1"][4], strict=True):
+    for a, b in zip(out["0"][4], out["1"][4], strict=True):               # the targets do not go through this path
         assert torch.equal(a, b)
+    # The batched finish adds a tap's split-K slabs in groups of 8, the stand-alone launch of a many-slab tap in groups
+    # of 32 (gram.hip): the same fp32 sums in another fixed order.  Scores to fp32 rounding; a Gram seed S (bf16) may
+    # differ in its last bit where the sum sat on a rounding boundary, and the gradient by what such a bit moves
+    # (the bound of test_first_layer_gram_fusion_is_equivalent).
+    for a, b in zip(out["0"][0], out["1"][0], strict=True):
+        assert b == pytest.approx(a, rel=2e-6)
+    for k, (a, b) in enumerate(zip(out["0"][3], out["1"][3], strict=True)):
+        d = (a.float() - b.float()).abs()
+        assert float((d / (2.0 ** -7 * torch.maximum(a.float().abs(), b.float().abs()) + 1e-30)).max()) <= 1.0, f"seed of tap {k}"
+        assert float((d > 0).float().mean()) <= 2e-2
+    err = float((out["1"][1] - out["0"][1]).abs().max() / out["0"][1].abs().max())
+    record_parity("vgg19_1024x1024_bf16", "gradient, Gram finish of the large taps batched vs stand-alone (of scale)", err, 2e-2)
+    assert err <= 2e-2
 
 
 def test_oracle_agreement_at_larger_size(monkeypatch):
