@@ -90,13 +90,19 @@ __device__ __forceinline__ f32x4 ld4_guard(const float* __restrict__ p, size_t i
   if (idx + 2 < n) v[2] = p[idx + 2];
   return v;
 }
+// history loads: NT = non-temporal (the history is streamed once per sweep: STV_LBFGS_NT bit 0 = sweep A, bit 1 = sweep B; A/B aid)
+template <bool NT>
+__device__ __forceinline__ f32x4 ldh4(const float* __restrict__ p) {
+  if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+  else return *reinterpret_cast<const f32x4*>(p);
+}
 typedef float pk2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float dot4(const f32x4& a, const f32x4& b) {
   return fmaf(a[0], b[0], fmaf(a[1], b[1], fmaf(a[2], b[2], a[3] * b[3])));
 }
 
 // ---- pass A ---------------------------------------------------------------------------------
-template <int U>
+template <int U, bool NT = false>
 __global__ __launch_bounds__(256) void pass_a_kernel(const float* __restrict__ g, const CState* st, CWs w,
                                                      size_t n, size_t nn, int hist, int nparts, int ntiles, int pgroups) {
   // blockIdx.x = pair group * ntiles + tile.  A small image has too few tiles to keep enough loads in flight
@@ -161,8 +167,8 @@ __global__ __launch_bounds__(256) void pass_a_kernel(const float* __restrict__ g
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const size_t idx = base + (size_t)(u * 256 + tid) * 4;
-      const f32x4 s4 = *reinterpret_cast<const f32x4*>(sj + idx);
-      const f32x4 y4 = *reinterpret_cast<const f32x4*>(yj + idx);
+      const f32x4 s4 = ldh4<NT>(sj + idx);
+      const f32x4 y4 = ldh4<NT>(yj + idx);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const double sd = (double)s4[e], yd = (double)y4[e];
@@ -553,7 +559,7 @@ __global__ __launch_bounds__(256) void solve_kernel(CState* st, CWs w, int hist,
 // fp64 inner products change nothing, fp64 accumulation HERE brings it to the reference's own level), so the
 // accumulators are double (ACC64): every product of two floats is exact in double, the sum is rounded to
 // fp32 once.  The sweep stays bandwidth-bound: 2 conversions + 2 DP FMAs per element and pair beside 8 bytes.
-template <int U, bool ACC64>
+template <int U, bool ACC64, bool NT = false>
 __global__ __launch_bounds__(256) void pass_b_kernel(float* __restrict__ x, const float* __restrict__ g,
                                                      const CState* st, CWs w, size_t n, size_t nn, int hist) {
   if (st->skip) return;
@@ -583,8 +589,8 @@ __global__ __launch_bounds__(256) void pass_b_kernel(float* __restrict__ x, cons
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const size_t idx = base + (size_t)(u * 256 + tid) * 4;
-      const f32x4 s4 = *reinterpret_cast<const f32x4*>(sj + idx);
-      const f32x4 y4 = *reinterpret_cast<const f32x4*>(yj + idx);
+      const f32x4 s4 = ldh4<NT>(sj + idx);
+      const f32x4 y4 = ldh4<NT>(yj + idx);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         if constexpr (ACC64) acc[u][e] = fma(cs, (double)s4[e], fma(cy, (double)y4[e], acc[u][e]));
@@ -666,12 +672,16 @@ extern "C" int stv_lbfgsc_dots(const float* grad, void* state, void* workspace, 
   hipStream_t st = static_cast<hipStream_t>(stream);
   CState* s = static_cast<CState*>(state);
   const StepGeom g = step_geom(workspace, n, history);
-  if (g.tile == 4096)
-    hipLaunchKernelGGL(pass_a_kernel<4>, dim3(g.ntiles * g.pgroups), dim3(256), 0, st, grad, s, g.w, n, g.nn, history, g.nparts, g.ntiles, g.pgroups);
-  else if (g.tile == 2048)
-    hipLaunchKernelGGL(pass_a_kernel<2>, dim3(g.ntiles * g.pgroups), dim3(256), 0, st, grad, s, g.w, n, g.nn, history, g.nparts, g.ntiles, g.pgroups);
-  else
-    hipLaunchKernelGGL(pass_a_kernel<1>, dim3(g.ntiles * g.pgroups), dim3(256), 0, st, grad, s, g.w, n, g.nn, history, g.nparts, g.ntiles, g.pgroups);
+  static const int nt_mask = getenv("STV_LBFGS_NT") ? atoi(getenv("STV_LBFGS_NT")) : 0;
+#define STV_LAUNCH_PASS_A(U_)                                                                                                      \
+  do {                                                                                                                             \
+    if (nt_mask & 1) hipLaunchKernelGGL((pass_a_kernel<U_, true>), dim3(g.ntiles * g.pgroups), dim3(256), 0, st, grad, s, g.w, n, g.nn, history, g.nparts, g.ntiles, g.pgroups); \
+    else hipLaunchKernelGGL((pass_a_kernel<U_, false>), dim3(g.ntiles * g.pgroups), dim3(256), 0, st, grad, s, g.w, n, g.nn, history, g.nparts, g.ntiles, g.pgroups);          \
+  } while (0)
+  if (g.tile == 4096) STV_LAUNCH_PASS_A(4);
+  else if (g.tile == 2048) STV_LAUNCH_PASS_A(2);
+  else STV_LAUNCH_PASS_A(1);
+#undef STV_LAUNCH_PASS_A
   hipLaunchKernelGGL(reduce_kernel, dim3(5 * m_max + NSCAL), dim3(256), 0, st, s, g.w, history, g.nparts);
   STV_CHECK_LAUNCH();
   return STV_OK;
@@ -694,9 +704,11 @@ extern "C" int stv_lbfgsc_apply(float* x, const float* grad, void* state, void* 
   static const bool acc64 = !(getenv("STV_LBFGS_ACC") && strcmp(getenv("STV_LBFGS_ACC"), "f32") == 0);
   const int tile_b = tile_floats_b(n);
   const int ntiles_b = (int)(g.nn / tile_b);
+  static const int nt_mask_b = getenv("STV_LBFGS_NT") ? atoi(getenv("STV_LBFGS_NT")) : 0;
 #define STV_LAUNCH_PASS_B(U_)                                                                                              \
   do {                                                                                                                     \
-    if (acc64) hipLaunchKernelGGL((pass_b_kernel<U_, true>), dim3(ntiles_b), dim3(256), 0, st, x, grad, s, g.w, n, g.nn, history); \
+    if (acc64 && (nt_mask_b & 2)) hipLaunchKernelGGL((pass_b_kernel<U_, true, true>), dim3(ntiles_b), dim3(256), 0, st, x, grad, s, g.w, n, g.nn, history); \
+    else if (acc64) hipLaunchKernelGGL((pass_b_kernel<U_, true>), dim3(ntiles_b), dim3(256), 0, st, x, grad, s, g.w, n, g.nn, history); \
     else hipLaunchKernelGGL((pass_b_kernel<U_, false>), dim3(ntiles_b), dim3(256), 0, st, x, grad, s, g.w, n, g.nn, history);      \
   } while (0)
   if (tile_b == 4096) STV_LAUNCH_PASS_B(4);

@@ -108,6 +108,32 @@ def test_a_table_the_library_rejects_is_ignored_not_fatal(monkeypatch, tmp_path)
     assert lib.stv_conv_tune_export(None, 0) == n_before and _lib.tile_table_info["entries"] == n_before
 
 
+def test_weight_stationary_kernel_selection_policy(monkeypatch):
+    """Which 3x3 launches take the weight-stationary kernel (host-side decision, no GPU needed: stv_conv_uses_ws): the
+    64 -> 64 layers always; 128 -> 128 only in the backward form (mask / Gram term) from 8 tiles of 2 x 32 pixels per
+    workgroup up - where it measured faster; STV_CONV_WS128 = 0 / 2 override; fp32 never."""
+    lib = _lib.load()
+    for var in ("STV_CONV_WS", "STV_CONV_WS128", "STV_CONV_CFG"):
+        monkeypatch.delenv(var, raising=False)
+    BF16, F32, MASK, RELU = _lib.STV_BF16, _lib.STV_F32, _lib.MASK, _lib.RELU_IN | _lib.RELU_OUT
+
+    def uses(H, cin, cout, dtype=BF16, flags=0, has_ref=0, has_pool=0):
+        return bool(lib.stv_conv_uses_ws(H, H, cin, cout, 9, dtype, flags | _lib.W_BLOCKED, has_ref, has_pool))
+    assert uses(1024, 64, 64, flags=RELU, has_pool=1) and uses(512, 64, 64, flags=MASK, has_ref=1)
+    assert not uses(512, 64, 128) and not uses(512, 64, 64, dtype=F32)
+    assert uses(512, 128, 128, flags=MASK, has_ref=1)              # conv2_2's backward at 1024^2: 4,096 tiles on 256 CUs
+    assert not uses(256, 128, 128, flags=MASK, has_ref=1)          # ... at 512^2: 4 tiles per workgroup
+    assert not uses(512, 128, 128, flags=RELU, has_pool=1)         # the forward form is no faster than the general kernel
+    monkeypatch.setenv("STV_CONV_WS128", "2")
+    assert uses(256, 128, 128, flags=MASK, has_ref=1) and uses(512, 128, 128, flags=RELU, has_pool=1)
+    assert not uses(512, 128, 256)
+    monkeypatch.setenv("STV_CONV_WS128", "0")
+    assert not uses(512, 128, 128, flags=MASK, has_ref=1)
+    monkeypatch.delenv("STV_CONV_WS128")
+    monkeypatch.setenv("STV_CONV_WS", "0")
+    assert not uses(1024, 64, 64, flags=RELU, has_pool=1)
+
+
 def test_bench_names_every_tile_configuration():
     """bench.py maps a tile index to the kernel instantiation rocprofv3 reports: its tables must cover every tile the
     library can choose (a new tile once crashed the bench with a KeyError)."""

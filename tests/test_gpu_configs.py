@@ -377,7 +377,7 @@ def test_configs4_200_adam_steps(tmp_path, monkeypatch):
       4K image in fp32 is 1.98 GiB per 64-channel activation, just inside the 32-bit buffer offsets, the strips a
       quarter of that: their agreement is also the largest-offset check of every kernel on the path;
     * the bf16 whole-image run: step ids / closure count / history length bit-exact over 200 steps, loss falls, its loss
-      at steps 100 / 200 within 2e-2 of the strip run's (two bf16 realisations of one trajectory), and the loss at its
+      at steps 100 / 200 within 1e-3 of the strip run's (two bf16 realisations of one trajectory; measured 2e-6), and the loss at its
       final image is the fp32 model's at that image up to bf16 storage (3e-2)."""
     from style_transfer_visualizer_amd import optimizers, spatial
     monkeypatch.setenv("STV_SYNTHETIC_WEIGHTS", "0")
@@ -476,9 +476,9 @@ def test_configs4_200_adam_steps(tmp_path, monkeypatch):
     assert np.isfinite(totals).all() and totals[-1] < totals[0] and torch.isfinite(out).all()
     for k in C4_MARKS:          # the strip run and the whole-image run: two bf16 realisations of the same 200 steps
         rel = abs(float(got[0]["scores"][k][2]) - totals[k - 1]) / abs(totals[k - 1])
-        record_parity(case, f"step {k}: total loss, bf16 strip run vs bf16 whole-image run (rel)", rel, 2e-2,
-                      "fused whole-image kernels and per-layer strip kernels round at the same points, in another order")
-        assert rel <= 2e-2
+        record_parity(case, f"step {k}: total loss, bf16 strip run vs bf16 whole-image run (rel)", rel, 1e-3,
+                      "fused whole-image kernels and per-layer strip kernels round at the same points, in another order (measured 2e-6)")
+        assert rel <= 1e-3
     # the loss logged at step 200 belongs to the image BEFORE the 200th update: re-evaluate both models at the final image
     s, c, t_bf = model_b.loss_and_grad(xb, 1e5, 1.0)
     xf = xb.detach().clone().requires_grad_(True)

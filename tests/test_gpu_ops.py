@@ -242,7 +242,7 @@ def test_conv_ws_forward_pool_and_backward(case, monkeypatch):
     cin, cout, H, W = case
     dtype = torch.bfloat16
     monkeypatch.setenv("STV_CONV_WS", "2")          # every supported shape, also those the default leaves to the general kernel
-    monkeypatch.setenv("STV_CONV_WS128", "1")
+    monkeypatch.setenv("STV_CONV_WS128", "2")       # (default: only the backward form of large images, where it measured faster)
     assert ops.conv_uses_ws(H, W, cin, cout, dtype, flags=ops.RELU_IN | ops.RELU_OUT | ops.W_BLOCKED)
     x = rnd((1, cin, H, W), 141)
     w = rnd((cout, cin, 3, 3), 142, -1, 1) * (2.0 / (9 * cin)) ** 0.5

@@ -1,5 +1,5 @@
 """conv2_2's two launches (128 -> 128 at half the image size: forward with ReLU-on-load + pool + arg-max map, pooled map
-only; backward = masked dgrad + Gram term) on the weight-stationary kernel (STV_CONV_WS128=1) and on the general kernel
+only; backward = masked dgrad + Gram term) on the weight-stationary kernel (STV_CONV_WS128=2) and on the general kernel
 (=0), interleaved in one process, back to back and behind 1 GB of unrelated traffic (the state the step leaves them in).
 
     python tools/ws128_probe.py [image size, default 1024]
@@ -55,7 +55,7 @@ def timed(fn, n=20, cold=False):
 gf_f = 2 * 9 * C * C * H * H / 1e9
 gf_b = 2 * (9 * C + C) * C * H * H / 1e9
 for rnd in range(3):
-    for ws in ("1", "0"):
+    for ws in ("2", "0"):
         os.environ["STV_CONV_WS128"] = ws
         os.environ["STV_CONV_WS"] = "1"
         uses = ops.conv_uses_ws(H, H, C, C, torch.bfloat16, flags=ops.RELU_IN | ops.RELU_OUT | ops.W_BLOCKED, has_pool=True)
