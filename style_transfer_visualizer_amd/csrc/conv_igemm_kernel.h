@@ -20,6 +20,9 @@
 #ifndef STV_HOLD_LAST
 #define STV_HOLD_LAST 1
 #endif
+#ifndef STV_X_AUX
+#define STV_X_AUX 0          // cache-policy bits of the input-tile DMA (diagnostic builds: 2 = nt); weights keep the default policy
+#endif
 #ifndef STV_STORE_AUX
 #define STV_STORE_AUX 0      // cache-policy bits of the output stores (diagnostic builds: 2 = nt, 16 = sc1)
 #endif
@@ -198,7 +201,8 @@ __device__ __forceinline__ void conv_mainloop(const Phase<typename C::Elem>& ph,
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<T*>(in ? ph.x : ph.w), 0, live ? (in ? x_bytes : w_bytes) : 0, 0x00020000);
     char* dst = buf + (g < C::PIECES ? g * 1024 : C::SPARE_OFF);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)dst, 16, p_off[j], stage * (in ? C::KB : w_stride), 0, 0);
+    if (STV_X_AUX != 0 && in) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)dst, 16, p_off[j], stage * C::KB, 0, STV_X_AUX);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)dst, 16, p_off[j], stage * (in ? C::KB : w_stride), 0, 0);
   };
 
   // lane-constant LDS byte offsets of this lane's fragments inside a stage buffer.  A: one per
@@ -422,7 +426,8 @@ __device__ __forceinline__ void conv_mainloop16(const Phase<bf16_t>& ph, const G
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<T*>(in ? ph.x : ph.w), 0, live ? (in ? x_bytes : w_bytes) : 0, 0x00020000);
     char* dst = pair + sub * C::STAGE_BYTES + (g < C::PIECES ? g * 1024 : C::SPARE_OFF);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)dst, 16, p_off[j], stage * (in ? C::KB : w_stride), 0, 0);
+    if (STV_X_AUX != 0 && in) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)dst, 16, p_off[j], stage * C::KB, 0, STV_X_AUX);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)dst, 16, p_off[j], stage * (in ? C::KB : w_stride), 0, 0);
   };
 
   // this lane's fragment addresses inside a slot pair: everything else is an immediate

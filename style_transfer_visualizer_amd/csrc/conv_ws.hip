@@ -40,6 +40,12 @@
 #ifndef STV_STORE_AUX
 #define STV_STORE_AUX 0      // cache-policy bits of the output stores (diagnostic builds: 2 = nt, 16 = sc1)
 #endif
+#ifndef STV_WS_X_AUX
+#define STV_WS_X_AUX 0       // cache-policy bits of the halo-tile DMA (diagnostic builds: 2 = nt)
+#endif
+#ifndef STV_WS_F_AUX
+#define STV_WS_F_AUX 0       // ... of the z-tile DMA (backward form: last use of that map in the step)
+#endif
 #ifndef STV_WS128_DEFAULT
 #define STV_WS128_DEFAULT 1  // the 128 -> 128 layer on this kernel unless STV_CONV_WS128=0
 #endif
@@ -183,7 +189,7 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgrou
         const int gy = y0 - 1 + (in_yx[p] >> 8), gx = x0 - 1 + (in_yx[p] & 255);
         const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
         const uint32_t off = ok ? (uint32_t)(base + in_rel[p]) : kOob;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr)(dst + p * 1024), 16, off, stage * KB, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr)(dst + p * 1024), 16, off, stage * KB, 0, STV_WS_X_AUX);
       }
     }
     if (DG) {
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgrou
           const int gy = y0 + p, gx = x0 + (lane >> 1);
           const bool ok = gy < a.H && gx < a.W;
           const uint32_t off = ok ? (uint32_t)((gy * a.W + gx) * (COUT * 2) + f_half * 16) : kOob;
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_f, (lds_ptr)(fdst + p * 1024), 16, off, stage * KB, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_f, (lds_ptr)(fdst + p * 1024), 16, off, stage * KB, 0, STV_WS_F_AUX);
         }
       }
     }
