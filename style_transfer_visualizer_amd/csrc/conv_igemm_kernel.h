@@ -335,6 +335,9 @@ __device__ __forceinline__ void conv_mainloop(const Phase<typename C::Elem>& ph,
     __builtin_amdgcn_s_barrier();
   };
 
+#if defined(STV_PRIO_HALF)   // diagnostic build: static priority for the second-dispatched half of an eight-wave workgroup (the arbitration loser)
+  if (C::NWAVES * C::KS == 8 && (int)(threadIdx.x >> 8) == 1) __builtin_amdgcn_s_setprio(1);
+#endif
   // prologue: rounds 0 .. NBUF-2 in flight, round 0 landed
 #pragma unroll
   for (int rnd = 0; rnd + 1 < C::NBUF; ++rnd)
