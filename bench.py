@@ -58,10 +58,10 @@ def conv_flops(meta) -> float:
 
 _CFG_NAMES = {0: "8, 128, 4, 2", 1: "8, 64, 4, 2", 2: "4, 128, 1, 4", 3: "4, 64, 2, 2", 4: "4, 64, 2, 2", 5: "8, 64, 4, 2", 6: "4, 64, 2, 2", 7: "2, 64, 2, 2", 8: "1, 64, 1, 2",
               9: "16, 64, 4, 2", 10: "16, 64, 4, 2", 11: "2, 32, 2, 1", 12: "4, 32, 4, 1",
-              13: "8, 64, 4, 2", 14: "16, 64, 4, 2", 15: "4, 64, 2, 2", 16: "2, 32, 2, 1", 17: "4, 32, 4, 1"}
+              13: "8, 64, 4, 2", 14: "16, 64, 4, 2", 15: "4, 64, 2, 2", 16: "2, 32, 2, 1", 17: "4, 32, 4, 1", 18: "16, 128, 4, 2"}
 _CFG_KS = {0: "1, 3, false", 1: "1, 3, false", 2: "1, 3, false", 3: "1, 3, false", 4: "2, 3, false", 5: "1, 2, false", 6: "1, 2, false", 7: "2, 3, false",
            8: "2, 3, false", 9: "1, 3, false", 10: "1, 2, false", 11: "2, 3, false", 12: "2, 3, false",
-           13: "1, 4, true", 14: "1, 4, true", 15: "1, 4, true", 16: "2, 4, true", 17: "2, 4, true"}      # (tests/test_abi.py keeps these two tables as long as the library's list of tiles)
+           13: "1, 4, true", 14: "1, 4, true", 15: "1, 4, true", 16: "2, 4, true", 17: "2, 4, true", 18: "1, 2, false"}      # (tests/test_abi.py keeps these two tables as long as the library's list of tiles)
 
 
 def kernel_group(meta, OP, dtype_code: int = 1, flags: int = 0) -> str | None:

@@ -100,15 +100,16 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs a) {
 // wave groups, 5 = 8x64 and 6 = 4x64 on a two-deep LDS ring (two / three workgroups per CU),
 // 7 = 2x64 with the K split (the 32x32-pixel layers: four times the workgroups of 4x64 x 2),
 // 8 = 1x64 with the K split in four-wave workgroups (a 32x32-pixel layer then covers all 256 CUs).  -1 = the shape is outside the matrix-core tiling (direct fallback).
-constexpr int kNumCfg = 18;     // 9 / 10 = 16x64 (four row blocks per wave: half the weight traffic per output) on the three- / two-deep ring
+constexpr int kNumCfg = 19;     // 9 / 10 = 16x64 (four row blocks per wave: half the weight traffic per output) on the three- / two-deep ring
 // 11 = 2x32 with the K split (four waves: 2 rows x 2 K groups): on a 32x32-pixel layer still one workgroup per CU, which
 // stages 434 KB instead of 1x64's 694 KB;  12 = the same on 4 rows (eight waves)
 // 13-17 = 8x64, 16x64, 4x64, 2x32 / K split, 4x32 / K split with the main loop on v_mfma_f32_16x16x32_bf16 (conv_igemm16.hip): two K-stages per
 // MFMA out of a ring of four stage slots; bf16 with cin % 32 == 0 only (fp32_cfg names the tile that serves the rest)
-const int kCfgTH[kNumCfg] = {8, 8, 4, 4, 4, 8, 4, 2, 1, 16, 16, 2, 4, 8, 16, 4, 2, 4},
-          kCfgBN[kNumCfg] = {128, 64, 128, 64, 64, 64, 64, 64, 64, 64, 64, 32, 32, 64, 64, 64, 32, 32};
+// 18 = 16x128 on the two-deep ring (also built in conv_igemm16.hip; bf16 only like its neighbours there)
+const int kCfgTH[kNumCfg] = {8, 8, 4, 4, 4, 8, 4, 2, 1, 16, 16, 2, 4, 8, 16, 4, 2, 4, 16},
+          kCfgBN[kNumCfg] = {128, 64, 128, 64, 64, 64, 64, 64, 64, 64, 64, 32, 32, 64, 64, 64, 32, 32, 128};
 constexpr int kFirstM16 = 13;
-bool is_m16(int cfg) { return cfg >= kFirstM16; }
+bool is_m16(int cfg) { return cfg >= kFirstM16; }       // (= "launched from conv_igemm16.hip": cin % 32 == 0, bf16)
 
 bool cfg_valid(int cfg, int cout) { return cfg >= 0 && cfg < kNumCfg && !(cout <= 64 && kCfgBN[cfg] == 128); }
 // fp32 (parity mode) keeps a second accumulator set per K-stage (blocked summation): the eight-wave tiles with 64+
@@ -122,6 +123,7 @@ int fp32_cfg(int cfg) {
     case 11: case 16: return 7;
     case 12: case 17: return 4;
     case 15: return 3;
+    case 18: return 2;
     default: return cfg;
   }
 }

@@ -14,6 +14,9 @@ int launch16(const ConvArgs& a, int cfg, hipStream_t st) {
     case 15: return launch_cfg<Cfg<T, 4, 64, 2, 2, TAPS, 1, 4, true>>(a, st);    // four waves
     case 16: return launch_cfg<Cfg<T, 2, 32, 2, 1, TAPS, 2, 4, true>>(a, st);    // the 32 x 32-pixel layers: K split over two wave groups
     case 17: return launch_cfg<Cfg<T, 4, 32, 4, 1, TAPS, 2, 4, true>>(a, st);
+    // 18: 16 rows x 128 couts on the two-deep ring (32x32x16 MFMAs; lives here only to build beside conv_igemm.hip): 0.58 of
+    // the 8x128 tile's LDS-DMA pieces per FLOP - the term that binds this kernel's issue port
+    case 18: return launch_cfg<Cfg<T, 16, 128, 4, 2, TAPS, 1, 2>>(a, st);
     default: return STV_ERR_ARG;
   }
 }

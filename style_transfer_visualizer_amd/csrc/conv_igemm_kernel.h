@@ -61,6 +61,10 @@ struct Cfg {
   static constexpr int MT = TH / WM;                 // image rows (32-pixel MFMA row blocks) per wave
   static constexpr int NT = BN / WN / 32;
   static constexpr int AROWS = MT + 2 * HALO;        // halo-tile rows a wave reads per horizontal tap
+  // BIG: eight 32x32 accumulator blocks per wave (128 registers of the 256 a wave has at two waves per SIMD): the bias
+  // is fetched after the main loop instead of being held through it (32 registers) and no tap step is held back across
+  // the stage barrier (24) - with them the 16x128 tile spilled 60 registers
+  static constexpr bool BIG = MT * NT >= 8;
   static constexpr int THREADS = GT * KS;
   // DMA pieces (one wave-instruction = 64 slots of 16 B = 32 rows): the halo tile rounded up to
   // whole pieces, then the weight rows; every wave of a group issues PPW pieces per stage (the
@@ -219,7 +223,11 @@ __device__ __forceinline__ void conv_mainloop(const Phase<typename C::Elem>& ph,
   const int b_lane = C::IN_BYTES + (wn * (C::NT * 32) + r) * C::KB + ((h ^ ((r >> 3) & 1)) << 4);
 
   constexpr int NSTEP = C::ND * C::ND;
-  constexpr int PER = (C::PPW + NSTEP - 1) / NSTEP;
+  // DMA pieces per tap step.  A two-deep ring under a workgroup that has the CU to itself (BIG) waits for the stage it
+  // requested during the SAME stage: all of it is requested in the first half of the steps, the second half is its slack
+  // (with two workgroups per CU - the other two-deep tiles - the partner covers that wait instead).
+  constexpr int NISS = (C::BIG && C::NBUF == 2 && NSTEP > 1) ? (NSTEP + 1) / 2 : NSTEP;
+  constexpr int PER = (C::PPW + NISS - 1) / NISS;
   // B fragments are fetched PFB steps ahead of their MFMAs: an LDS read takes ~190 cycles under
   // load, a step only MT*NT*32 of MFMA issue, so a lone wave on a SIMD needs the deeper queue
   constexpr int PFB = (C::MT * C::NT >= 4) ? 2 : 3;
@@ -239,7 +247,7 @@ __device__ __forceinline__ void conv_mainloop(const Phase<typename C::Elem>& ph,
   // in a fresh accumulator that is then added to the running sum - chains of 72 and Cin/8 instead of 9 Cin.
   // Speed is not the point of this mode (no held-back step either: it would straddle two stage sums).
   constexpr bool BLOCKED = sizeof(T) == 4;
-  constexpr int NHOLD = BLOCKED ? 0 : ((STV_HOLD_LAST < NSTEP) ? STV_HOLD_LAST : NSTEP);      // steps held back (0: none)
+  constexpr int NHOLD = (BLOCKED || C::BIG) ? 0 : ((STV_HOLD_LAST < NSTEP) ? STV_HOLD_LAST : NSTEP);      // steps held back (0: none)
   FragT hold_a[NHOLD > 0 ? NHOLD : 1][C::MT], hold_b[NHOLD > 0 ? NHOLD : 1][C::NT];
 #pragma unroll
   for (int q = 0; q < NHOLD; ++q) {
@@ -587,15 +595,18 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
   const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.bias), 0, a.bias != nullptr ? a.cout * 4 : 0, 0x00020000);
   f32x4 bias_v[C::NT][4];           // channels past cout (and a null bias) read as zero
+  auto load_bias = [&]() {
 #pragma unroll
-  for (int nt = 0; nt < C::NT; ++nt)
+    for (int nt = 0; nt < C::NT; ++nt)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int nn = n0 + wn_ * (C::NT * 32) + nt * 32 + 8 * j + 4 * (lane >> 5);
-      const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (uint32_t)(nn * 4), 0, 0);
+      for (int j = 0; j < 4; ++j) {
+        const int nn = n0 + wn_ * (C::NT * 32) + nt * 32 + 8 * j + 4 * (lane >> 5);
+        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (uint32_t)(nn * 4), 0, 0);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) bias_v[nt][j][e] = __uint_as_float(t[e]);
-    }
+        for (int e = 0; e < 4; ++e) bias_v[nt][j][e] = __uint_as_float(t[e]);
+      }
+  };
+  if constexpr (!C::BIG) load_bias();
 
   f32x16 acc[C::MT][C::NT];
 #pragma unroll
@@ -682,6 +693,7 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
     }
   }
 
+  if constexpr (C::BIG) load_bias();
   // the next conv's weights: one 128-byte line per lane (lines past the end: no traffic), consumed at the very end
   const __amdgpu_buffer_rsrc_t rs_pf = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.pf), 0, (int)a.pf_bytes, 0x00020000);
   const uint32_t pf_word = __builtin_amdgcn_raw_buffer_load_b32(rs_pf, ((uint32_t)blockIdx.x * C::THREADS + (uint32_t)tid) * 128u, 0, 0);

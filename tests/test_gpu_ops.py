@@ -164,7 +164,7 @@ def test_conv_igemm_forward(dtype, case, flags, blocked):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [None, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17])
+@pytest.mark.parametrize("cfg", [None, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18])
 @pytest.mark.parametrize("flags", [0, ops.MASK, ops.ACCUM, ops.MASK | ops.ACCUM])
 @pytest.mark.parametrize("case", [(128, 64, 33, 70), (256, 128, 16, 40), (64, 64, 9, 33), (512, 256, 8, 8),
                                   (96, 48, 20, 36)])   # 48 channels: not whole multi-slice stages -> general 1x1 loop
@@ -172,7 +172,7 @@ def test_conv_igemm_dual_dgrad_plus_gram_term(dtype, cfg, flags, case, monkeypat
     """out = [prev +] mask(z>0) * dgrad(dy, w) + F . S^T in one launch: the mask touches the first term only."""
     cd, cs, H, W = case            # channels of the layer above (dy) and of this layer (output, F, S)
     if cfg is not None:
-        if cs <= 64 and cfg in (0, 2):
+        if cs <= 64 and cfg in (0, 2, 18):
             pytest.skip("128-channel tiles need more than 64 output channels")
         monkeypatch.setenv("STV_CONV_CFG", str(cfg))
     w = rnd((cd, cs, 3, 3), 71, -1, 1) * (2.0 / (9 * cd)) ** 0.5
@@ -196,13 +196,13 @@ def test_conv_igemm_dual_dgrad_plus_gram_term(dtype, cfg, flags, case, monkeypat
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [None, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17])
+@pytest.mark.parametrize("cfg", [None, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18])
 @pytest.mark.parametrize("case", [(64, 64, 33, 70), (128, 128, 16, 40), (64, 128, 9, 33), (256, 256, 8, 8)])
 def test_conv_igemm_with_fused_maxpool(dtype, cfg, case, monkeypatch):
     """One launch writes relu(conv) and MaxPool2d(2,2) of it (odd sizes drop the last row / column like torch)."""
     cin, cout, H, W = case
     if cfg is not None:
-        if cout <= 64 and cfg in (0, 2):
+        if cout <= 64 and cfg in (0, 2, 18):
             pytest.skip("128-channel tiles need more than 64 output channels")
         monkeypatch.setenv("STV_CONV_CFG", str(cfg))
     x = rnd((1, cin, H, W), 51)
@@ -308,7 +308,7 @@ def test_conv_ws_forward_pool_and_backward(case, monkeypatch):
         assert float((d / (2.0 ** -7 * torch.maximum(out.float().abs(), out_gen.float().abs()) + 1e-6)).max()) <= 1.0
 
 
-@pytest.mark.parametrize("cfg", [None, 0, 1, 3, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17])
+@pytest.mark.parametrize("cfg", [None, 0, 1, 3, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18])
 @pytest.mark.parametrize("case", [(128, 64, 32, 64), (256, 128, 16, 40), (512, 512, 8, 8), (512, 256, 12, 20)])
 def test_conv_igemm_route_equals_dgrad_then_pool_backward(cfg, case, monkeypatch):
     """stv_conv_igemm_route: the dgrad of the conv behind a max-pool writes the pre-pool gradient directly.
@@ -317,7 +317,7 @@ def test_conv_igemm_route_equals_dgrad_then_pool_backward(cfg, case, monkeypatch
     cd, cs, H, W = case                      # dy channels (the conv's Cout), routed channels (its Cin), pooled size
     dtype = torch.bfloat16
     if cfg is not None:
-        if cs <= 64 and cfg in (0, 2):
+        if cs <= 64 and cfg in (0, 2, 18):
             pytest.skip("128-channel tiles need more than 64 output channels")
         monkeypatch.setenv("STV_CONV_CFG", str(cfg))
     # a forward conv + pool produces a genuine arg-max map (with ties from the ReLU zeros)
@@ -365,12 +365,12 @@ def test_conv_ws_matches_the_general_kernel(monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18])
 @pytest.mark.parametrize("case", [(128, 128, 21, 70), (64, 64, 9, 33), (48, 136, 12, 40), (512, 128, 8, 8)])
 def test_conv_igemm_every_tile_config(dtype, cfg, case, monkeypatch):
     """Each tile shape / wave layout / K split (forced with STV_CONV_CFG) on full, ragged and odd-K shapes."""
     cin, cout, H, W = case
-    if cout <= 64 and cfg in (0, 2):
+    if cout <= 64 and cfg in (0, 2, 18):
         pytest.skip("128-channel tiles need more than 64 output channels")
     monkeypatch.setenv("STV_CONV_CFG", str(cfg))
     x = rnd((1, cin, H, W), 41)
