@@ -866,21 +866,17 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
     if constexpr (C::MT % 2 == 0) if (a.pool != nullptr) {     // (a wave must own both rows of a pooling window)
       const int Hp = a.H >> 1, Wp = a.W >> 1;
       const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(a.pool, 0, Hp * Wp * a.cout * (int)sizeof(T), 0x00020000);
-      f32x16 pm[C::MT / 2][C::NT];
-#pragma unroll
-      for (int mp = 0; mp < C::MT / 2; ++mp)
-#pragma unroll
-        for (int nt = 0; nt < C::NT; ++nt)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const float v = fmaxf(acc[2 * mp][nt][i], acc[2 * mp + 1][nt][i]);
-            pm[mp][nt][i] = fmaxf(v, __shfl_xor(v, 1, 64));
-          }
+      // the pooled sums are formed where they are consumed (a [MT/2][NT] array of them would be 64 more registers on
+      // the 16x128 tile, on top of 128 accumulators: it spilled)
+      auto pooled = [&](int mp, int nt, int i) -> float {
+        const float v = fmaxf(acc[2 * mp][nt][i], acc[2 * mp + 1][nt][i]);
+        return fmaxf(v, __shfl_xor(v, 1, 64));
+      };
       auto pool_off = [&](int mp) -> uint32_t {
         const int gyp = ((y0 + wm * C::MT) >> 1) + mp, gxp = (x0 + r) >> 1;
         return ((r & 1) == 0 && gyp < Hp && gxp < Wp) ? (uint32_t)(((gyp * Wp + gxp) * a.cout) * (int)sizeof(T)) : kOob;
       };
-      emit([&](int mp, int nt, int i) { return pm[mp < C::MT / 2 ? mp : 0][nt][i]; }, pool_off, rs_p, C::MT / 2, false, false);
+      emit([&](int mp, int nt, int i) { return pooled(mp < C::MT / 2 ? mp : 0, nt, i); }, pool_off, rs_p, C::MT / 2, false, false);
 
       // Arg-max map for the pooling backward (stv_maxpool_bwd with STV_POOL_IDX): per pooled element
       // one byte, bits 0-1 = window position of the FIRST maximum in scan order (row-major, torch),
