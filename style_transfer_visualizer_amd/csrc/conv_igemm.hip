@@ -303,8 +303,10 @@ int tune_typed(int H, int W, int cin, int cout, int key_taps, hipStream_t st) {
   int best = base;
   float t_best = 3.4e38f, t_base = 3.4e38f;
   int rc = STV_OK;
-  int ncfg = kNumCfg;
-  if (const char* lim = getenv("STV_CONV_TUNE_CFGS")) ncfg = atoi(lim) < kNumCfg ? atoi(lim) : kNumCfg;   // A/B aid
+  // The 16x128 tile (18) is not offered by default: it wins the hot loop by 7-9 % on every shape with >= 512 tiles and
+  // LOSES in the step (round 4: closure +1.9 % at 1024^2 with it on the 256^2 layers, nothing at 3840x2160) - see DESIGN 3.8
+  int ncfg = kNumCfg - 1;
+  if (const char* lim = getenv("STV_CONV_TUNE_CFGS")) ncfg = atoi(lim) < kNumCfg ? atoi(lim) : kNumCfg;   // A/B aid (19: every tile)
   // two interleaved rounds, the faster time of each configuration counts: one round's order effects
   // (clock ramp after the fill, a neighbour's tail) otherwise decide between near-equal tiles
   float t_cfg[kNumCfg];
