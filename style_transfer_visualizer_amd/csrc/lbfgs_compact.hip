@@ -167,7 +167,10 @@ __global__ __launch_bounds__(256) void pass_a_kernel(const float* __restrict__ g
     // that overshot leaves y ~ 1e25 in the history: y_j . y_c ~ 1e50), and torch's vector recursion - which
     // never forms these inner products - stays finite there.  A product of two floats is exact in double.
     // The sweep stays bandwidth-bound (8 bytes per element and pair beside 5 DP FMAs + conversions).
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0;
+    // (the fourth product of a pair, y_j . s_c, fills the table entry s_c . y_j of a NEWER s with an OLDER y - an entry the
+    //  recursion never reads (solve_kernel: only s_i . y_j with i older than j) - so it is not computed: its slot in the
+    //  5-per-pair layout stays, as a zero)
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a4 = 0.0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const size_t idx = base + (size_t)(u * 256 + tid) * 4;
@@ -176,18 +179,17 @@ __global__ __launch_bounds__(256) void pass_a_kernel(const float* __restrict__ g
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const double sd = (double)s4[e], yd = (double)y4[e];
-        const double gd = (double)gv[u][e], cd = (double)yv[u][e], dd = (double)sv[u][e];
+        const double gd = (double)gv[u][e], cd = (double)yv[u][e];
         a0 = fma(sd, gd, a0);   // s_j . g
         a1 = fma(yd, gd, a1);   // y_j . g
         a2 = fma(sd, cd, a2);   // s_j . y_c
-        a3 = fma(yd, dd, a3);   // y_j . s_c
         a4 = fma(yd, cd, a4);   // y_j . y_c
       }
     }
-    a0 = wave_sum_d_dpp(a0); a1 = wave_sum_d_dpp(a1); a2 = wave_sum_d_dpp(a2); a3 = wave_sum_d_dpp(a3); a4 = wave_sum_d_dpp(a4);
+    a0 = wave_sum_d_dpp(a0); a1 = wave_sum_d_dpp(a1); a2 = wave_sum_d_dpp(a2); a4 = wave_sum_d_dpp(a4);
     if (lane == 0) {
       double* o = w.part + (size_t)(jj * 5) * nparts + p;
-      o[0] = a0; o[(size_t)nparts] = a1; o[(size_t)2 * nparts] = a2; o[(size_t)3 * nparts] = a3;
+      o[0] = a0; o[(size_t)nparts] = a1; o[(size_t)2 * nparts] = a2; o[(size_t)3 * nparts] = 0.0;
       o[(size_t)4 * nparts] = a4;
     }
   }
