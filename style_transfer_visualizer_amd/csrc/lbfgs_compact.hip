@@ -24,6 +24,10 @@
 
 #include "stv_common.h"
 
+#ifndef STV_LBFGS_PIPE_DEFAULT
+#define STV_LBFGS_PIPE_DEFAULT 0      // sweep A with the next pair's loads in flight (STV_LBFGS_PIPE=1); set from the measurement
+#endif
+
 namespace {
 
 constexpr int MAX_HIST = 128;
@@ -106,7 +110,7 @@ __device__ __forceinline__ float dot4(const f32x4& a, const f32x4& b) {
 }
 
 // ---- pass A ---------------------------------------------------------------------------------
-template <int U, bool NT = false>
+template <int U, bool NT = false, bool PIPE = false>
 __global__ __launch_bounds__(256) void pass_a_kernel(const float* __restrict__ g, const CState* st, CWs w,
                                                      size_t n, size_t nn, int hist, int nparts, int ntiles, int pgroups) {
   // blockIdx.x = pair group * ntiles + tile.  A small image has too few tiles to keep enough loads in flight
@@ -159,38 +163,84 @@ __global__ __launch_bounds__(256) void pass_a_kernel(const float* __restrict__ g
   const int p = tile_idx * 4 + wave;
   const int per = (m + pgroups - 1) / pgroups;
   const int j_end = (pgrp + 1) * per < m ? (pgrp + 1) * per : m;
-  for (int jj = pgrp * per; jj < j_end; ++jj) {
+  // Double accumulators: a product of two fp32 history / gradient vectors can leave the fp32 range (a step
+  // that overshot leaves y ~ 1e25 in the history: y_j . y_c ~ 1e50), and torch's vector recursion - which
+  // never forms these inner products - stays finite there.  A product of two floats is exact in double.
+  // (the fourth product of a pair, y_j . s_c, fills the table entry s_c . y_j of a NEWER s with an OLDER y - an entry the
+  //  recursion never reads (solve_kernel: only s_i . y_j with i older than j) - so it is not computed: its slot in the
+  //  5-per-pair layout stays, as a zero)
+  // PIPE: the next pair's loads are in flight while this pair is multiplied (two register sets; affordable since the
+  // unused product went: 160 registers = the three waves per SIMD the grid gives anyway).
+  auto load_pair = [&](int jj, f32x4 (&s4)[U], f32x4 (&y4)[U]) {
     const int slot = (head + jj) % S;
     const float* __restrict__ sj = w.S + (size_t)slot * nn;
     const float* __restrict__ yj = w.Y + (size_t)slot * nn;
-    // Double accumulators: a product of two fp32 history / gradient vectors can leave the fp32 range (a step
-    // that overshot leaves y ~ 1e25 in the history: y_j . y_c ~ 1e50), and torch's vector recursion - which
-    // never forms these inner products - stays finite there.  A product of two floats is exact in double.
-    // The sweep stays bandwidth-bound (8 bytes per element and pair beside 5 DP FMAs + conversions).
-    // (the fourth product of a pair, y_j . s_c, fills the table entry s_c . y_j of a NEWER s with an OLDER y - an entry the
-    //  recursion never reads (solve_kernel: only s_i . y_j with i older than j) - so it is not computed: its slot in the
-    //  5-per-pair layout stays, as a zero)
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a4 = 0.0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const size_t idx = base + (size_t)(u * 256 + tid) * 4;
-      const f32x4 s4 = ldh4<NT>(sj + idx);
-      const f32x4 y4 = ldh4<NT>(yj + idx);
+      s4[u] = ldh4<NT>(sj + idx);
+      y4[u] = ldh4<NT>(yj + idx);
+    }
+  };
+  auto dot_pair = [&](int jj, const f32x4 (&s4)[U], const f32x4 (&y4)[U]) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a4 = 0.0;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const double sd = (double)s4[e], yd = (double)y4[e];
+        const double sd = (double)s4[u][e], yd = (double)y4[u][e];
         const double gd = (double)gv[u][e], cd = (double)yv[u][e];
         a0 = fma(sd, gd, a0);   // s_j . g
         a1 = fma(yd, gd, a1);   // y_j . g
         a2 = fma(sd, cd, a2);   // s_j . y_c
         a4 = fma(yd, cd, a4);   // y_j . y_c
       }
-    }
     a0 = wave_sum_d_dpp(a0); a1 = wave_sum_d_dpp(a1); a2 = wave_sum_d_dpp(a2); a4 = wave_sum_d_dpp(a4);
     if (lane == 0) {
       double* o = w.part + (size_t)(jj * 5) * nparts + p;
       o[0] = a0; o[(size_t)nparts] = a1; o[(size_t)2 * nparts] = a2; o[(size_t)3 * nparts] = 0.0;
       o[(size_t)4 * nparts] = a4;
+    }
+  };
+  if constexpr (PIPE) {
+    f32x4 sA[U], yA[U], sB[U], yB[U];
+    int jj = pgrp * per;
+    if (jj < j_end) load_pair(jj, sA, yA);
+    for (; jj < j_end; jj += 2) {
+      if (jj + 1 < j_end) load_pair(jj + 1, sB, yB);
+      dot_pair(jj, sA, yA);
+      if (jj + 1 < j_end) {
+        if (jj + 2 < j_end) load_pair(jj + 2, sA, yA);
+        dot_pair(jj + 1, sB, yB);
+      }
+    }
+  } else {
+    for (int jj = pgrp * per; jj < j_end; ++jj) {
+      const int slot = (head + jj) % S;
+      const float* __restrict__ sj = w.S + (size_t)slot * nn;
+      const float* __restrict__ yj = w.Y + (size_t)slot * nn;
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a4 = 0.0;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const size_t idx = base + (size_t)(u * 256 + tid) * 4;
+        const f32x4 s4 = ldh4<NT>(sj + idx);
+        const f32x4 y4 = ldh4<NT>(yj + idx);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const double sd = (double)s4[e], yd = (double)y4[e];
+          const double gd = (double)gv[u][e], cd = (double)yv[u][e];
+          a0 = fma(sd, gd, a0);   // s_j . g
+          a1 = fma(yd, gd, a1);   // y_j . g
+          a2 = fma(sd, cd, a2);   // s_j . y_c
+          a4 = fma(yd, cd, a4);   // y_j . y_c
+        }
+      }
+      a0 = wave_sum_d_dpp(a0); a1 = wave_sum_d_dpp(a1); a2 = wave_sum_d_dpp(a2); a4 = wave_sum_d_dpp(a4);
+      if (lane == 0) {
+        double* o = w.part + (size_t)(jj * 5) * nparts + p;
+        o[0] = a0; o[(size_t)nparts] = a1; o[(size_t)2 * nparts] = a2; o[(size_t)3 * nparts] = 0.0;
+        o[(size_t)4 * nparts] = a4;
+      }
     }
   }
   if (pgrp != 0) return;
@@ -679,9 +729,11 @@ extern "C" int stv_lbfgsc_dots(const float* grad, void* state, void* workspace, 
   CState* s = static_cast<CState*>(state);
   const StepGeom g = step_geom(workspace, n, history);
   static const int nt_mask = getenv("STV_LBFGS_NT") ? atoi(getenv("STV_LBFGS_NT")) : 3;
+  static const int pipe_a = getenv("STV_LBFGS_PIPE") ? atoi(getenv("STV_LBFGS_PIPE")) : STV_LBFGS_PIPE_DEFAULT;
 #define STV_LAUNCH_PASS_A(U_)                                                                                                      \
   do {                                                                                                                             \
-    if (nt_mask & 1) hipLaunchKernelGGL((pass_a_kernel<U_, true>), dim3(g.ntiles * g.pgroups), dim3(256), 0, st, grad, s, g.w, n, g.nn, history, g.nparts, g.ntiles, g.pgroups); \
+    if ((nt_mask & 1) && pipe_a) hipLaunchKernelGGL((pass_a_kernel<U_, true, true>), dim3(g.ntiles * g.pgroups), dim3(256), 0, st, grad, s, g.w, n, g.nn, history, g.nparts, g.ntiles, g.pgroups); \
+    else if (nt_mask & 1) hipLaunchKernelGGL((pass_a_kernel<U_, true>), dim3(g.ntiles * g.pgroups), dim3(256), 0, st, grad, s, g.w, n, g.nn, history, g.nparts, g.ntiles, g.pgroups); \
     else hipLaunchKernelGGL((pass_a_kernel<U_, false>), dim3(g.ntiles * g.pgroups), dim3(256), 0, st, grad, s, g.w, n, g.nn, history, g.nparts, g.ntiles, g.pgroups);          \
   } while (0)
   if (g.tile == 4096) STV_LAUNCH_PASS_A(4);
