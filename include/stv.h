@@ -128,7 +128,8 @@ int stv_conv_tune_import(const int* in7, int n_entries);
 
 /* Hint for the NEXT stv_conv_igemm* launch issued from this thread: `bytes` of weights that the conv launched AFTER
  * it will read.  That next launch touches them (one 128-byte line per lane, between its main loop and its epilogue) so
- * they are on chip when their own launch starts.  The caller clears the hint (NULL / 0) after the launch.  No
+ * they are on chip when their own launch starts.  One shot: the launch that follows on this thread consumes the hint
+ * (whichever kernel serves it), so a hint can never reach a later, unrelated launch; the tile tuner runs without one.  No
  * counterpart in the reference (cuDNN / oneDNN own their weights' residency). */
 void stv_conv_next_weights(const void* w, size_t bytes);
 

@@ -209,7 +209,11 @@ int launch_mfma(const ConvArgs& a, int cfg, hipStream_t st) {
 template <typename T, int TAPS>
 int launch_typed(const ConvArgs& a, hipStream_t st) {
   // short-K layers (Cin = 64, bf16): weight-stationary persistent kernel (conv_ws.hip)
-  if (stv_conv_ws_supported(a, elem_traits<T>::kDtype, TAPS)) return stv_conv_ws_launch(a, st);
+  if (stv_conv_ws_supported(a, elem_traits<T>::kDtype, TAPS)) {
+    g_stv_next_w = nullptr;        // (the weight-stationary kernel does not touch ahead: the hint is consumed, not left for a later launch)
+    g_stv_next_w_bytes = 0;
+    return stv_conv_ws_launch(a, st);
+  }
   int cfg = choose_cfg(a.H, a.W, a.cin, a.cout, (int)sizeof(T), TAPS);
   if ((cfg == 7 || cfg == 8 || cfg == 11 || cfg == 12 || cfg == 16 || cfg == 17) && a.pool != nullptr) cfg = 4;      // one row per wave: no pooling window
   if (cfg < 0) {

@@ -934,6 +934,8 @@ int launch_cfg(const ConvArgs& a_in, hipStream_t st) {
   ConvArgs a = a_in;
   a.pf = g_stv_next_w;
   a.pf_bytes = g_stv_next_w ? g_stv_next_w_bytes : 0;
+  g_stv_next_w = nullptr;          // one shot: the hint belongs to THIS launch, whatever launches next on the thread starts without one
+  g_stv_next_w_bytes = 0;
   const bool relu = (a.flags & STV_RELU_IN) != 0;
   const void* fn = relu ? reinterpret_cast<const void*>(&conv_igemm_kernel<C, true>)
                         : reinterpret_cast<const void*>(&conv_igemm_kernel<C, false>);
