@@ -336,16 +336,35 @@ class Schedule:
         self._keep.append(table)                    # the host array must outlive stv_program_create
         return self._op(op=OP_GRAM_MULTI, p0=ctypes.addressof(table), n=len(specs))
 
+    def _route_candidate(self, nd: Node, producer: dict) -> Node | None:
+        """The pool node whose backward can ride in the dgrad of conv `nd` (everything about that decision that does
+        not depend on what has been written so far): `nd`'s input is a pooled map with an arg-max byte map, no tap on
+        it, no mask, no Gram term on this launch (`backward_ops` adds: nothing wrote the pre-pool gradient yet)."""
+        s, d = nd.src, nd.dst
+        if nd.kind != "conv" or s is None or os.environ.get("STV_FUSE_POOL_BWD", "1") == "0":
+            return None
+        mask_src = nd.relu_in or (s.relu_fused and not s.taps)
+        pool_nd = producer.get(id(s))
+        if (pool_nd is None or pool_nd.kind != "pool" or pool_nd.idx is None or self.dtype != torch.bfloat16
+                or nd.wb is None or nd.wb.dim() != 4 or s.taps or mask_src
+                or pool_nd.src.H != 2 * s.H or pool_nd.src.W != 2 * s.W
+                or 4 * s.act.numel() * s.act.element_size() >= 2 ** 31
+                or d.act.numel() * d.act.element_size() >= 2 ** 31):
+            return None
+        return pool_nd
+
     def alloc_grads(self) -> None:
         """Gradient storage of every activation.  The reverse schedule is a chain - the op of node i reads the gradient
         of node i's output and writes that of node i - 1's (i - 2's when the pooling backward rides in a dgrad's
-        epilogue) - so on one GPU the gradients ROTATE through three slabs (node i's in slab i mod 3) instead of each
-        owning memory that is touched once per step: a dgrad then writes into lines that were in use two launches ago and
-        are still in the Infinity Cache, not into lines last seen a step ago (`tools/cold_probe2.py`: a conv whose
+        epilogue) - so on one GPU the gradients ROTATE through a few slabs instead of each owning memory that is touched
+        once per step: the walk below follows the reverse schedule and hands every gradient the slab that was released
+        LAST (the one the previous launch read), so a dgrad writes into lines that were in use one launch ago and are
+        still on chip (Infinity Cache), not into lines last seen a step ago (`tools/cold_probe2.py`: a conv whose
         output range was just written runs 10-15 % faster than one storing to cold memory), and the working set of the
-        backward pass shrinks from the sum of all gradients to three times the largest.  A buffer with a content tap
-        keeps a tensor of its own (its gradient is written during the forward half).  Row strips keep one tensor per
-        node (their halo rows are exchanged by address).  `STV_GRAD_ARENA=0`: one tensor per node everywhere."""
+        backward pass shrinks from the sum of all gradients to two or three times the largest.  A buffer with a content
+        tap keeps a tensor of its own (its gradient is written during the forward half).  Row strips keep one tensor
+        per node (their halo rows are exchanged by address).  `STV_GRAD_ARENA=0`: one tensor per node everywhere;
+        `backward_ops` checks, op by op, that no slab is read after somebody else wrote it."""
         todo = [nd for nd in self.nodes if nd.dst.grad is None]
         if not todo:
             return
@@ -357,17 +376,55 @@ class Schedule:
                 nd.dst.grad = torch.zeros_like(nd.dst.act) if self.halo else torch.empty_like(nd.dst.act)
             return
         own = {id(t.buf) for t in self.content_taps}
-        rot = [nd.dst for nd in self.nodes if id(nd.dst) not in own]
+        producer = {id(n.dst): n for n in self.nodes}
+        slab_of: dict[int, int] = {}       # id(buf) -> slab number
+        free: list[int] = []               # released slabs, the most recently released last
+        n_slabs = 0
+
+        def take(buf: Buf) -> None:
+            nonlocal n_slabs
+            if id(buf) in own or id(buf) in slab_of:
+                return
+            if free:
+                slab_of[id(buf)] = free.pop()
+            else:
+                slab_of[id(buf)] = n_slabs
+                n_slabs += 1
+
+        def release(buf: Buf) -> None:
+            if id(buf) in slab_of:
+                free.append(slab_of[id(buf)])
+
+        routed: set[int] = set()
+        unused: list[Buf] = []
+        for nd in reversed(self.nodes):
+            d = nd.dst
+            if id(nd) in routed:           # the pooled map's gradient is never formed
+                unused.append(d)
+                continue
+            take(d)                        # (the deepest activation: first written by its own taps)
+            if nd.kind != "conv_first":
+                pool_nd = self._route_candidate(nd, producer)
+                if pool_nd is not None and not any(t.kind == "content" for t in pool_nd.src.taps):
+                    take(pool_nd.src)
+                    routed.add(id(pool_nd))
+                else:
+                    take(nd.src)
+            release(d)
+        rot = [nd.dst for nd in self.nodes if id(nd.dst) in slab_of]
         nbytes = max((b.act.numel() * b.act.element_size() for b in rot), default=0)
         nbytes = (nbytes + 4095) // 4096 * 4096
-        self._grad_slabs = torch.empty(3, nbytes, device=self.device, dtype=torch.uint8)
-        for i, nd in enumerate(self.nodes):
+        self._grad_slabs = torch.empty(max(n_slabs, 1), nbytes, device=self.device, dtype=torch.uint8)
+        self._grad_slab_of = slab_of
+        for nd in self.nodes:
             b = nd.dst
-            if id(b) in own:
-                b.grad = torch.empty_like(b.act)
-            else:
+            if id(b) in slab_of:
                 n = b.act.numel() * b.act.element_size()
-                b.grad = self._grad_slabs[i % 3, :n].view(b.act.dtype).view(b.act.shape)
+                b.grad = self._grad_slabs[slab_of[id(b)], :n].view(b.act.dtype).view(b.act.shape)
+            elif b in unused:
+                b.grad = self._grad_slabs[0, :0].view(b.act.dtype)       # never read or written
+            else:
+                b.grad = torch.empty_like(b.act)
 
     def backward_ops(self, x_grad: torch.Tensor, *, style_coef: float, content_coef: float,
                      coef_dev: torch.Tensor | None, prewritten: tuple = ()) -> list[StvOp]:
@@ -386,9 +443,24 @@ class Schedule:
         n_style = len(self.style_taps)
         fuse_gram = os.environ.get("STV_FUSE_GRAM", "1") != "0"      # A/B knob
         fused_taps: set[int] = set()     # style taps whose dF = F.S rides in the dgrad that shares their buffer
-        fuse_route = os.environ.get("STV_FUSE_POOL_BWD", "1") != "0"      # A/B knob
         routed: set[int] = set()         # pool nodes whose backward rides in the dgrad of the conv behind them
         producer = {id(n.dst): n for n in self.nodes}
+        # gradients that share a slab (alloc_grads): whoever reads one must find its own writer's data there
+        slab_of = getattr(self, "_grad_slab_of", {})
+        holder: dict[int, int] = {}      # slab -> id(buf) of its last writer
+
+        def wr(buf: Buf) -> torch.Tensor:
+            if id(buf) in slab_of:
+                if id(buf) in written and holder.get(slab_of[id(buf)]) != id(buf):
+                    raise RuntimeError("internal: gradient slab overwritten before its accumulation")
+                holder[slab_of[id(buf)]] = id(buf)
+            return buf.grad
+
+        def rd(buf: Buf) -> torch.Tensor:
+            if id(buf) in slab_of and holder.get(slab_of[id(buf)]) != id(buf):
+                raise RuntimeError("internal: gradient slab overwritten before its reader ran")
+            return buf.grad
+
         for nd in reversed(self.nodes):
             d = nd.dst
             if id(nd) in routed:         # its consumer's dgrad already wrote nd.src.grad
@@ -399,11 +471,11 @@ class Schedule:
                 if tap.kind == "style":
                     if d.act.is_cuda:
                         ops.conv_tune(d.H, d.W, d.C, d.C, 1, self.dtype)     # cached per shape
-                    out.append(self._op(op=OP_CONV, p0=d.act, p1=tap.sgrad, q0=d.grad, H=d.H, W=d.W,
+                    out.append(self._op(op=OP_CONV, p0=d.act, p1=tap.sgrad, q0=wr(d), H=d.H, W=d.W,
                                         cin=d.C, cout=d.C, taps=1, flags=acc_flag(d)))
                 else:
                     cd = coef_dev[n_style + tap.order:] if coef_dev is not None else None
-                    out.append(self._op(op=OP_CONTENT_GRAD, p0=d.act, p1=tap.target, p2=cd, q0=d.grad,
+                    out.append(self._op(op=OP_CONTENT_GRAD, p0=d.act, p1=tap.target, p2=cd, q0=wr(d),
                                         n=d.act.numel(), f0=content_coef, flags=acc_flag(d)))
                 written.add(id(d))
             if id(d) not in written:
@@ -411,10 +483,10 @@ class Schedule:
                 raise RuntimeError(msg)
             if d.relu_fused and d.taps:
                 # taps see relu(z): mask the summed gradient once, in place
-                out.append(self._op(op=OP_RELU_BWD, p0=d.act, p1=d.grad, q0=d.grad, n=d.act.numel()))
+                out.append(self._op(op=OP_RELU_BWD, p0=d.act, p1=rd(d), q0=d.grad, n=d.act.numel()))
             s = nd.src
             if nd.kind == "conv_first":
-                out.append(self._op(op=OP_CONV_FIRST_DGRAD, p0=d.grad, p1=nd.wf, p2=nd.wb, q0=x_grad, H=d.H, W=d.W,
+                out.append(self._op(op=OP_CONV_FIRST_DGRAD, p0=rd(d), p1=nd.wf, p2=nd.wb, q0=x_grad, H=d.H, W=d.W,
                                     cin=nd.cin, cout=d.C))
                 continue
             mask_src = nd.relu_in or (s.relu_fused and not s.taps)
@@ -430,18 +502,13 @@ class Schedule:
                 # s is a pooled map (arg-max byte map available, nothing else contributes to its gradient):
                 # the dgrad's epilogue routes straight into the pre-pool gradient - no pooled-resolution
                 # gradient, no pooling-backward pass
-                pool_nd = producer.get(id(s))
-                if (fuse_route and gram is None and pool_nd is not None and pool_nd.kind == "pool" and pool_nd.idx is not None
-                        and self.dtype == torch.bfloat16 and nd.wb.dim() == 4 and not s.taps and not mask_src
-                        and id(s) not in written and pool_nd.src.H == 2 * s.H and pool_nd.src.W == 2 * s.W
-                        and id(pool_nd.src) not in written
-                        and 4 * s.act.numel() * s.act.element_size() < 2 ** 31
-                        and d.grad.numel() * d.grad.element_size() < 2 ** 31):
+                pool_nd = self._route_candidate(nd, producer)
+                if (gram is None and pool_nd is not None and id(s) not in written and id(pool_nd.src) not in written):
                     ps = pool_nd.src
-                    if d.grad.is_cuda:
+                    if d.act.is_cuda:
                         ops.conv_tune(s.H, s.W, d.C, s.C, ops.TUNE_ROUTE, self.dtype)     # cached per shape
                     rflags = (MASK if (ps.relu_fused and not ps.taps) else 0) | W_BLOCKED | POOL_ROUTE
-                    out.append(self._op(op=OP_CONV, p0=d.grad, p1=nd.wb, p2=pool_nd.idx, q1=ps.grad, H=s.H, W=s.W,
+                    out.append(self._op(op=OP_CONV, p0=rd(d), p1=nd.wb, p2=pool_nd.idx, q1=wr(ps), H=s.H, W=s.W,
                                         cin=d.C, cout=s.C, taps=9, flags=rflags))
                     routed.add(id(pool_nd))
                     written.add(id(s))
@@ -449,23 +516,23 @@ class Schedule:
                     continue
                 if gram is not None:
                     fused_taps.add(id(gram))
-                    out.append(self._op(op=OP_CONV, p0=d.grad, p1=nd.wb, p3=s.act if mask_src else None, q0=s.grad,
+                    out.append(self._op(op=OP_CONV, p0=rd(d), p1=nd.wb, p3=s.act if mask_src else None, q0=wr(s),
                                         q2=s.act, q3=gram.sgrad, n=s.C, H=s.H, W=s.W, cin=d.C, cout=s.C, taps=9,
                                         flags=flags))
                 else:
-                    out.append(self._op(op=OP_CONV, p0=d.grad, p1=nd.wb, p3=s.act if mask_src else None, q0=s.grad,
+                    out.append(self._op(op=OP_CONV, p0=rd(d), p1=nd.wb, p3=s.act if mask_src else None, q0=wr(s),
                                         H=s.H, W=s.W, cin=d.C, cout=s.C, taps=9, flags=flags))
             elif nd.kind == "pool":
                 flags = (MASK if (s.relu_fused and not s.taps) else 0) | acc_flag(s)
                 if nd.idx is not None:      # written by the forward conv that carried this pool
-                    out.append(self._op(op=OP_POOL_BWD, p0=nd.idx, p1=d.grad, q0=s.grad, H=s.H, W=s.W, cin=s.C,
+                    out.append(self._op(op=OP_POOL_BWD, p0=nd.idx, p1=rd(d), q0=wr(s), H=s.H, W=s.W, cin=s.C,
                                         flags=flags | POOL_IDX))
                 else:
                     s_i = self.interior(s.act)
-                    out.append(self._op(op=OP_POOL_BWD, p0=s_i, p1=self.interior(d.grad), q0=self.interior(s.grad),
+                    out.append(self._op(op=OP_POOL_BWD, p0=s_i, p1=self.interior(rd(d)), q0=self.interior(wr(s)),
                                         H=s_i.shape[0], W=s.W, cin=s.C, flags=flags))
             else:  # materialised relu
-                out.append(self._op(op=OP_RELU_BWD, p0=s.act, p1=d.grad, q0=s.grad, n=s.act.numel(),
+                out.append(self._op(op=OP_RELU_BWD, p0=s.act, p1=rd(d), q0=wr(s), n=s.act.numel(),
                                     flags=acc_flag(s)))
             written.add(id(s))
         _ = style_coef

@@ -227,16 +227,17 @@ def test_bf16_every_stored_tensor_within_one_ulp_of_the_oracle_op(size, monkeypa
             assert torch.equal(nd.dst.act, nd2.dst.act), f"L{nd.layer:02d} {nd.kind}: stored activation differs"
         if nd.idx is not None:
             assert torch.equal(nd.idx, nd2.idx), f"L{nd.layer:02d}: arg-max map differs"
-    # the gradients of the default run share three rotating slabs: only the last writer of each slab is still there
-    # (and the image gradient above is every one of them pushed through the rest of the chain)
+    # the gradients of the default run rotate through a few slabs (two here: every pooling backward rides in a dgrad, so
+    # the reverse schedule reads one gradient and writes one): only the last writer of each slab is still there (and the
+    # image gradient above is every one of them pushed through the rest of the chain)
     slabs = eng2.sched._grad_slabs
     own = [nd2 for nd2 in eng2.sched.nodes if nd2.dst.grad.untyped_storage().data_ptr() != slabs.untyped_storage().data_ptr()]
     assert len(own) == 1 and own[0].dst.taps and own[0].dst.taps[0].kind == "content"
-    for i in range(min(3, len(nodes))):          # nodes 0, 1, 2 wrote their slabs last
-        if not (routed and nodes[i].kind == "pool"):
-            assert torch.equal(nodes[i].dst.grad, eng2.sched.nodes[i].dst.grad), f"L{nodes[i].layer:02d}: gradient differs"
+    assert slabs.shape[0] == 2, slabs.shape
+    for i in range(2):                           # conv1_1's and conv1_2's outputs: the last writers of the two slabs
+        assert torch.equal(nodes[i].dst.grad, eng2.sched.nodes[i].dst.grad), f"L{nodes[i].layer:02d}: gradient differs"
     skipped_mb = sum(nd.dst.act.numel() * 2 for nd in skipped) / 1e6
     record_parity(case, "pre-pool maps not stored (STV_POOL_ONLY): everything else vs the all-stored run", 0.0, 0.0,
-                  f"bit-identical scores, image gradient, {len(nodes) - 4} activations, arg-max maps; gradients rotating through 3 slabs of {slabs.shape[1] / 1e6:.0f} MB; {skipped_mb:.0f} MB of stores dropped per closure")
+                  f"bit-identical scores, image gradient, {len(nodes) - 4} activations, arg-max maps; gradients rotating through {slabs.shape[0]} slabs of {slabs.shape[1] / 1e6:.0f} MB; {skipped_mb:.0f} MB of stores dropped per closure")
     del model, x, model2, x2
     torch.cuda.empty_cache()
