@@ -25,6 +25,10 @@ struct ConvArgs {
   // them between its main loop and its epilogue, so that launch finds them on chip instead of in HBM.
   const void* pf = nullptr;
   uint32_t pf_bytes = 0;
+  // how many XCDs share one spatial tile (1, 2 or 4; conv_igemm_kernel.h, block decode): 1 = every channel block of a
+  // tile on the tile's XCD (each L2 fetches ALL weights, the input once), g = the channel blocks dealt to g XCDs
+  // (each L2 fetches 1/g of the weights, the input g times)
+  int xshare = 1;
 };
 
 // conv_ws.hip: weight-stationary persistent kernel for 3x3, Cin = 64, bf16 (the short-K layers).

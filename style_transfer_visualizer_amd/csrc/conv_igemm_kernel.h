@@ -573,8 +573,19 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
     const int grp8 = b / round, within = b - grp8 * round;
     const int left = ntiles - grp8 * 8;                    // tiles in this group of (up to) eight
     const int span = left < 8 ? left : 8;
-    tile = grp8 * 8 + within % span;
-    yb = within / span;
+    const int g = a.xshare;
+    if (g > 1 && span == 8 && ny % g == 0) {
+      // g XCDs share a tile: XCD x = unit * g + part works on the tiles {unit, unit + 8/g, ...} of the group and on
+      // the channel blocks [part * ny/g, (part + 1) * ny/g) - its L2 holds 1/g of the weights (a layer's 4.7 MB of
+      // 512 x 512 x 9 bf16 weights do not fit one 4-MB L2; half of them do)
+      const int xcd = within & 7, slot = within >> 3, nyp = ny / g;
+      const int unit = xcd / g, part = xcd - unit * g;
+      tile = grp8 * 8 + unit + (8 / g) * (slot / nyp);
+      yb = part * nyp + slot % nyp;
+    } else {
+      tile = grp8 * 8 + within % span;
+      yb = within / span;
+    }
   }
   const int tile_x = tile % tiles_x;
   const int tile_y = tile / tiles_x;
@@ -936,6 +947,16 @@ int launch_cfg(const ConvArgs& a_in, hipStream_t st) {
   a.pf_bytes = g_stv_next_w ? g_stv_next_w_bytes : 0;
   g_stv_next_w = nullptr;          // one shot: the hint belongs to THIS launch, whatever launches next on the thread starts without one
   g_stv_next_w_bytes = 0;
+  {
+    // XCDs per spatial tile (ConvArgs::xshare).  STV_CONV_XSHARE: 1 / 2 / 4 forces it; default: the weights of one
+    // workgroup generation's channel blocks should fit an XCD's 4-MB L2 beside the input tiles
+    static const int forced = getenv("STV_CONV_XSHARE") ? atoi(getenv("STV_CONV_XSHARE")) : 0;
+    const int ny = ceil_div(a.cout, C::BN);
+    int g = forced > 0 ? forced : 1;
+    if (g != 1 && g != 2 && g != 4) g = 1;
+    while (g > 1 && ny % g != 0) g >>= 1;
+    a.xshare = g;
+  }
   const bool relu = (a.flags & STV_RELU_IN) != 0;
   const void* fn = relu ? reinterpret_cast<const void*>(&conv_igemm_kernel<C, true>)
                         : reinterpret_cast<const void*>(&conv_igemm_kernel<C, false>);
