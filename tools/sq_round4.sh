@@ -11,3 +11,9 @@ for spec in "256 256 256 256 0" "256 256 256 256 14" "128 128 512 512 1" "128 12
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/sq4_$1_$2_$3_$4_$5 -- python3 tools/conv_one.py $1 $2 $3 $4 $5 20 > /dev/null 2> $R/gpurun_out/sq4_$1_$2_$3_$4_$5.err
   echo "sq $spec done"
 done
+# conv2_2 (128 -> 128 at 512^2): forward + pool and backward (mask + Gram term), weight-stationary and general kernel in one pass
+rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/sq4_ws128_1024 -- python3 tools/ws128_probe.py 1024 > /dev/null 2> $R/gpurun_out/sq4_ws128_1024.err
+echo "sq ws128 done"
+# conv1_2 (64 -> 64 at 1024^2) on the weight-stationary kernel: tools/ws_probe.py
+rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/sq4_ws64_1024 -- python3 tools/ws_probe.py > /dev/null 2> $R/gpurun_out/sq4_ws64_1024.err
+echo "sq ws64 done"
