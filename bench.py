@@ -320,6 +320,58 @@ def run_gpu(args, rank: int, world: int, device: torch.device, size: int, steps:
     return info
 
 
+def run_in_flight(device: torch.device, size: int, k: int, steps: int) -> dict:
+    """K independent images on ONE GPU, each through its own OptimizationRunner on its own host thread and stream
+    (what `main.style_transfer_batch` does with a rank's pairs): aggregate steps/s at a full L-BFGS history.  An extra
+    leg - the headline `value` is one image per GPU, as BASELINE.json's configs are."""
+    import threading
+
+    from style_transfer_visualizer_amd import config as stv_config
+    from style_transfer_visualizer_amd import core_model, optimization, synthetic
+    gate = threading.Barrier(k)
+    marks = [{} for _ in range(k)]
+    setup = threading.Lock()
+    errors: list = []
+
+    def work(i: int) -> None:
+        try:
+            torch.cuda.set_device(device)
+            cfg = stv_config.StyleTransferConfig.model_validate({})
+            oc = cfg.optimization
+            oc.steps, oc.init_method = HISTORY_SIZE + 10 + steps, "random"
+            cfg.hardware.precision = "bf16"
+            cfg.video.create_video, cfg.video.final_only = False, True
+            with setup:
+                torch.manual_seed(oc.seed + i)
+                content = synthetic.synthetic_image(2 * i, size, size).to(device)
+                style = synthetic.synthetic_image(2 * i + 1, size, size).to(device)
+                model, x, opt = core_model.prepare_model_and_input(content, style, device, oc, precision="bf16")
+
+            def on_end(m):
+                if m.step == HISTORY_SIZE + 10:
+                    torch.cuda.synchronize(device)
+                    gate.wait(timeout=300)
+                    marks[i]["t0"] = time.perf_counter()
+                elif m.step == HISTORY_SIZE + 10 + steps:
+                    torch.cuda.synchronize(device)
+                    marks[i]["t1"] = time.perf_counter()
+            optimization.OptimizationRunner(model, x, cfg, optimizer=opt, progress_bar=_Bar(),
+                                            callbacks=optimization.OptimizationCallbacks(on_step_end=on_end)).run()
+        except BaseException as exc:      # noqa: BLE001 - reported by the caller
+            errors.append(exc)
+            gate.abort()
+    threads = [threading.Thread(target=work, args=(i,), name=f"stv-image-{i}") for i in range(k)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    span = max(m["t1"] for m in marks) - min(m["t0"] for m in marks)
+    return {"images": k, "size": size, "steps_each": steps, "aggregate_steps_per_s": round(k * steps / span, 2),
+            "ms_per_step_of_each_image": round(1e3 * span / steps, 4)}
+
+
 def run_spatial(args, rank: int, world: int, device: torch.device) -> dict:
     """BASELINE configs[4]: ONE 3840x2160 image, Adam, row strips across the N GPUs (strong scaling)."""
     import torch.distributed as dist
@@ -567,6 +619,15 @@ def main() -> None:
                                                "hist_len": fp32["lbfgs"].get("hist_len"), "fill_steps": STEADY_FILL,
                                                "timed_steps": STEADY_STEPS, "precision": "fp32"}}
 
+    in_flight = None
+    if not args.no_extra and args.size == 512 and world == 1 and rank == 0:
+        # several independent images on the one GPU (main.style_transfer_batch's default is 2 in flight)
+        legs = [run_in_flight(device, 512, 2, 150), run_in_flight(device, 512, 3, 150), run_in_flight(device, 1024, 2, 60)]
+        in_flight = {"note": ("independent images in flight on ONE GPU, one host thread + stream each: one image's L-BFGS update "
+                              "(HBM-bound) overlaps another's closure (matrix-core / issue-bound); aggregate steps/s at a full "
+                              "history; NOT the headline (BASELINE configs are one image per GPU)"),
+                     "legs": legs}
+
     def step_summary(e: dict, steps_per_s: float) -> dict:
         """The three yardsticks of one workload, for the `roofline` object (the driver's record keeps that object)."""
         out = {"steps_per_s": round(steps_per_s, 2)}
@@ -638,6 +699,10 @@ def main() -> None:
             line["steady_state"] = steady
         if extra is not None:
             line["extra_1024"] = extra
+        if in_flight is not None:
+            line["images_in_flight"] = in_flight
+            if roof is not None:            # the driver's record keeps `roofline`: the aggregate figures go there too
+                roof["images_in_flight_steps_per_s"] = {f"{g['size']}x{g['size']} x{g['images']}": g["aggregate_steps_per_s"] for g in in_flight["legs"]}
         if world == 1 and not args.no_cpu_baseline:
             cpu = host_cpu()
             # BASELINE.md §4 asks for the node's physical cores; on a many-core host the reference's CPU path is

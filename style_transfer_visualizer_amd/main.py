@@ -7,6 +7,7 @@ with a warning and the run proceeds like ``--no-video``.
 """
 from __future__ import annotations
 
+import threading
 from pathlib import Path
 
 import torch
@@ -14,6 +15,10 @@ import torch
 from . import core_model, image_io, optimization, runtime
 from .logging_utils import logger
 from .type_defs import InputPaths, SaveOptions
+
+# Several images may be in flight in one process (style_transfer_batch): seeding the global generators and drawing
+# the start image from them is one step per image, as in a sequential run.
+_SETUP_LOCK = threading.Lock()
 
 
 def style_transfer(paths: InputPaths, config, *, video_writer=None, gif_collector=None) -> torch.Tensor:
@@ -31,14 +36,14 @@ def style_transfer(paths: InputPaths, config, *, video_writer=None, gif_collecto
         config.video.create_video = video_writer is not None
         config.video.create_gif = gif_collector is not None
 
-    runtime.setup_random_seed(config.optimization.seed)
     device = runtime.setup_device(config.hardware.device)
     normalize = config.optimization.normalize
     content_img = image_io.load_image_to_tensor(paths.content_path, device, normalize=normalize)
     style_img = image_io.load_image_to_tensor(paths.style_path, device, normalize=normalize)
-
-    model, input_img, optimizer = core_model.prepare_model_and_input(
-        content_img, style_img, device, config.optimization, precision=config.hardware.precision)
+    with _SETUP_LOCK:
+        runtime.setup_random_seed(config.optimization.seed)
+        model, input_img, optimizer = core_model.prepare_model_and_input(
+            content_img, style_img, device, config.optimization, precision=config.hardware.precision)
 
     output_path = runtime.setup_output_directory(config.output.output)
     content_name, style_name = Path(paths.content_path).stem, Path(paths.style_path).stem
@@ -57,13 +62,15 @@ def style_transfer(paths: InputPaths, config, *, video_writer=None, gif_collecto
     return input_img.detach().clamp(0, 1)
 
 
-def style_transfer_batch(pairs: list[InputPaths], config) -> list[torch.Tensor]:
+def style_transfer_batch(pairs: list[InputPaths], config, *, images_per_gpu: int | None = None) -> list[torch.Tensor]:
     """Several INDEPENDENT content/style pairs, one process per GPU (launch with torchrun).
 
     Not a tensor batch - ``gram_matrix`` folds a batch dimension into channels (reference
     core_model.py:56-57) - but N replicas of the single-image path: rank r runs pairs r, r + world, ...
     each with its own model targets and L-BFGS state, writes their PNGs, and one all-gather at the end
     hands every rank the full ordered list of result images (they must share one size).
+    ``images_per_gpu`` of a rank's pairs run at the same time, each on its own stream (default 2:
+    ``parallel.images_in_flight``) - same results, one image's optimizer update overlaps another's closure.
     """
     import copy  # noqa: PLC0415
 
@@ -75,4 +82,4 @@ def style_transfer_batch(pairs: list[InputPaths], config) -> list[torch.Tensor]:
 
     def one(_index: int, paths: InputPaths) -> torch.Tensor:
         return style_transfer(paths, copy.deepcopy(config)).contiguous()
-    return parallel.run_sharded(list(pairs), one)
+    return parallel.run_sharded(list(pairs), one, concurrent=images_per_gpu)

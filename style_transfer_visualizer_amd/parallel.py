@@ -87,14 +87,41 @@ def gather_results(local: list[tuple[int, torch.Tensor]], n_items: int) -> list[
     return out
 
 
-def run_sharded(items: list, fn, *, backend: str | None = None) -> list:
+def images_in_flight(n_local: int, requested: int | None = None) -> int:
+    """How many of this rank's images run at the same time (each on its own host thread and stream).
+
+    One image leaves the GPU half idle in two different ways - its closure is bound by the matrix cores and their
+    instruction issue, its L-BFGS update by HBM - so two or three independent images on one GPU overlap one's update
+    with another's closure: `tools/two_images_probe.py`, one MI355X, aggregate steps/s at 512^2 1,181 -> 1,354 (2 images)
+    -> 1,476 (3), at 1024^2 390 -> 424 (2).  Default 2 on a GPU (``STV_IMAGES_PER_GPU``), 1 on the CPU; the results do
+    not depend on it (every kernel of a step is deterministic and an image shares nothing with its neighbours)."""
+    if requested is None:
+        requested = int(os.environ.get("STV_IMAGES_PER_GPU", "2" if torch.cuda.is_available() else "1"))
+    return max(1, min(int(requested), n_local))
+
+
+def run_sharded(items: list, fn, *, backend: str | None = None, concurrent: int | None = 1) -> list:
     """Run ``fn(index, item) -> Tensor`` on this rank's share of ``items`` (round-robin) and return the
     results of ALL items, in order, on every rank (one all-gather at the end; no collective in between).
 
     This is BASELINE configs[3]'s pattern - N independent content/style pairs, one per GPU - as a library
     call: ``main.style_transfer_batch`` and ``bench.py --gpus N`` are thin callers.  Works without a
-    process group too (one process runs every item).
+    process group too (one process runs every item).  ``concurrent``: images of this rank in flight at once
+    (``images_in_flight``; ``None`` = its default); worker threads inherit the caller's GPU.
     """
     rank, _local, world = init_distributed(backend)
-    local = [(i, fn(i, items[i])) for i in shard_items(len(items), rank, world)]
+    mine = shard_items(len(items), rank, world)
+    k = images_in_flight(len(mine), concurrent) if mine else 1
+    if k <= 1:
+        local = [(i, fn(i, items[i])) for i in mine]
+    else:
+        from concurrent.futures import ThreadPoolExecutor  # noqa: PLC0415
+        dev = torch.cuda.current_device() if torch.cuda.is_available() else None
+
+        def worker(i: int):
+            if dev is not None:
+                torch.cuda.set_device(dev)          # the current device is per thread
+            return i, fn(i, items[i])
+        with ThreadPoolExecutor(max_workers=k, thread_name_prefix="stv-image") as pool:
+            local = list(pool.map(worker, mine))
     return gather_results(local, len(items))

@@ -302,11 +302,22 @@ def test_style_transfer_batch_runs_independent_pairs(tmp_path, monkeypatch):
     cfg.hardware.device = "cuda"
     pairs = [InputPaths(content_path=str(tmp_path / "c0.png"), style_path=str(tmp_path / "s.png")),
              InputPaths(content_path=str(tmp_path / "c1.png"), style_path=str(tmp_path / "s.png"))]
-    out = stv_main.style_transfer_batch(pairs, cfg)
+    out = stv_main.style_transfer_batch(pairs, cfg, images_per_gpu=1)
     assert len(out) == 2 and all(t.shape == (1, 3, 64, 64) for t in out)
     assert all(float(t.min()) >= 0.0 and float(t.max()) <= 1.0 for t in out)
     assert not torch.equal(out[0], out[1])
     assert (tmp_path / "out" / "stylized_c0_x_s.png").is_file() and (tmp_path / "out" / "stylized_c1_x_s.png").is_file()
+    # several images of a rank in flight at once (each on its own host thread and stream; the default is 2): the same
+    # images, bit for bit - the seeded start image is drawn under a lock, and nothing else is shared
+    from style_transfer_visualizer_amd import parallel
+    assert parallel.images_in_flight(5) == 2 and parallel.images_in_flight(1) == 1 and parallel.images_in_flight(5, 3) == 3
+    five = pairs + pairs[::-1] + pairs[:1]
+    seq = stv_main.style_transfer_batch(five, cfg, images_per_gpu=1)
+    for k in (2, 3):
+        cfg.output.output = str(tmp_path / f"out{k}")
+        par = stv_main.style_transfer_batch(five, cfg, images_per_gpu=k)
+        assert len(par) == 5 and all(torch.equal(a, b) for a, b in zip(seq, par, strict=True)), f"{k} images in flight"
+    assert torch.equal(seq[0], out[0]) and torch.equal(seq[1], out[1]) and torch.equal(seq[3], out[0])
 
 
 # ------------------------------------------------------------------- a2/a5 replaced content targets

@@ -63,3 +63,29 @@ def test_single_process_paths():
     assert torch.equal(out[0], torch.zeros(2)) and torch.equal(out[1], torch.ones(2))
     res = parallel.run_sharded(["a", "bb", "ccc"], lambda i, item: torch.tensor([float(len(item) + i)]))
     assert [float(t) for t in res] == [1.0, 3.0, 5.0]
+
+
+def test_several_items_in_flight_keep_their_order(monkeypatch):
+    """``run_sharded(..., concurrent=k)``: k of a rank's items run at once on worker threads; results stay in item order
+    whatever order they finish in, and the number in flight follows the argument / STV_IMAGES_PER_GPU / the item count."""
+    import threading
+    import time
+    seen, lock = {"now": 0, "peak": 0, "threads": set()}, threading.Lock()
+
+    def fn(i, item):
+        with lock:
+            seen["now"] += 1
+            seen["peak"] = max(seen["peak"], seen["now"])
+            seen["threads"].add(threading.current_thread().name)
+        time.sleep(0.02 * (5 - i))                 # later items finish first
+        with lock:
+            seen["now"] -= 1
+        return torch.tensor([float(item)])
+    res = parallel.run_sharded([3.0, 1.0, 4.0, 1.5, 9.0], fn, concurrent=3)
+    assert [float(t) for t in res] == [3.0, 1.0, 4.0, 1.5, 9.0]
+    assert seen["peak"] == 3 and all(n.startswith("stv-image") for n in seen["threads"])
+    assert parallel.images_in_flight(4, 1) == 1 and parallel.images_in_flight(2, 8) == 2 and parallel.images_in_flight(0, 3) == 1
+    monkeypatch.setenv("STV_IMAGES_PER_GPU", "3")
+    assert parallel.images_in_flight(10) == 3
+    monkeypatch.delenv("STV_IMAGES_PER_GPU")
+    assert parallel.images_in_flight(10) == (2 if torch.cuda.is_available() else 1)
