@@ -673,9 +673,11 @@ inline int lanes_shift(int cout, int kvec) {
   return s;
 }
 
-// scratch for the repacked first-layer weights (2 x 1728 floats), allocated once per process
+// scratch for the repacked first-layer weights (2 x 1728 floats) of callers that did not pre-pack them
+// (stv_conv_first_pack), allocated once per HOST THREAD: several images may be in flight in one process, each driven
+// by its own thread on its own stream, and a repack on one stream must not overwrite what a conv on another reads
 float* first_scratch() {
-  static float* p = nullptr;
+  thread_local float* p = nullptr;
   if (!p && hipMalloc(reinterpret_cast<void**>(&p), 2 * 1728 * sizeof(float)) != hipSuccess) p = nullptr;
   return p;
 }
