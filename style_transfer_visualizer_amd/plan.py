@@ -396,11 +396,11 @@ class Schedule:
                 free.append(slab_of[id(buf)])
 
         routed: set[int] = set()
-        unused: list[Buf] = []
+        unused: set[int] = set()
         for nd in reversed(self.nodes):
             d = nd.dst
             if id(nd) in routed:           # the pooled map's gradient is never formed
-                unused.append(d)
+                unused.add(id(d))
                 continue
             take(d)                        # (the deepest activation: first written by its own taps)
             if nd.kind != "conv_first":
@@ -421,7 +421,7 @@ class Schedule:
             if id(b) in slab_of:
                 n = b.act.numel() * b.act.element_size()
                 b.grad = self._grad_slabs[slab_of[id(b)], :n].view(b.act.dtype).view(b.act.shape)
-            elif b in unused:
+            elif id(b) in unused:
                 b.grad = self._grad_slabs[0, :0].view(b.act.dtype)       # never read or written
             else:
                 b.grad = torch.empty_like(b.act)
