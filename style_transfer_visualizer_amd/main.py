@@ -69,7 +69,7 @@ def style_transfer_batch(pairs: list[InputPaths], config, *, images_per_gpu: int
     core_model.py:56-57) - but N replicas of the single-image path: rank r runs pairs r, r + world, ...
     each with its own model targets and L-BFGS state, writes their PNGs, and one all-gather at the end
     hands every rank the full ordered list of result images (they must share one size).
-    ``images_per_gpu`` of a rank's pairs run at the same time, each on its own stream (default 2:
+    ``images_per_gpu`` of a rank's pairs run at the same time, each on its own stream (default 3:
     ``parallel.images_in_flight``) - same results, one image's optimizer update overlaps another's closure.
     """
     import copy  # noqa: PLC0415

@@ -92,11 +92,11 @@ def images_in_flight(n_local: int, requested: int | None = None) -> int:
 
     One image leaves the GPU half idle in two different ways - its closure is bound by the matrix cores and their
     instruction issue, its L-BFGS update by HBM - so two or three independent images on one GPU overlap one's update
-    with another's closure: `tools/two_images_probe.py`, one MI355X, aggregate steps/s at 512^2 1,181 -> 1,354 (2 images)
-    -> 1,476 (3), at 1024^2 390 -> 424 (2).  Default 2 on a GPU (``STV_IMAGES_PER_GPU``), 1 on the CPU; the results do
-    not depend on it (every kernel of a step is deterministic and an image shares nothing with its neighbours)."""
+    with another's closure: `tools/two_images_probe.py`, one MI355X, aggregate steps/s by images in flight 1 / 2 / 3 / 4: 256^2 2,172 / 3,079 /
+    3,429; 512^2 1,145 / 1,311 / 1,446 / 1,352; 1024^2 384 / 419 / 421 / 407.  Default 3 on a GPU
+    (``STV_IMAGES_PER_GPU``), 1 on the CPU; the results do not depend on it (every kernel of a step is deterministic and an image shares nothing with its neighbours)."""
     if requested is None:
-        requested = int(os.environ.get("STV_IMAGES_PER_GPU", "2" if torch.cuda.is_available() else "1"))
+        requested = int(os.environ.get("STV_IMAGES_PER_GPU", "3" if torch.cuda.is_available() else "1"))
     return max(1, min(int(requested), n_local))
 
 

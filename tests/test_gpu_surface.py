@@ -307,10 +307,10 @@ def test_style_transfer_batch_runs_independent_pairs(tmp_path, monkeypatch):
     assert all(float(t.min()) >= 0.0 and float(t.max()) <= 1.0 for t in out)
     assert not torch.equal(out[0], out[1])
     assert (tmp_path / "out" / "stylized_c0_x_s.png").is_file() and (tmp_path / "out" / "stylized_c1_x_s.png").is_file()
-    # several images of a rank in flight at once (each on its own host thread and stream; the default is 2): the same
+    # several images of a rank in flight at once (each on its own host thread and stream; the default is 3): the same
     # images, bit for bit - the seeded start image is drawn under a lock, and nothing else is shared
     from style_transfer_visualizer_amd import parallel
-    assert parallel.images_in_flight(5) == 2 and parallel.images_in_flight(1) == 1 and parallel.images_in_flight(5, 3) == 3
+    assert parallel.images_in_flight(5) == 3 and parallel.images_in_flight(1) == 1 and parallel.images_in_flight(5, 2) == 2
     three = pairs + pairs[:1]
     for k in (2, 3):
         cfg.output.output = str(tmp_path / f"out{k}")

@@ -88,4 +88,4 @@ def test_several_items_in_flight_keep_their_order(monkeypatch):
     monkeypatch.setenv("STV_IMAGES_PER_GPU", "3")
     assert parallel.images_in_flight(10) == 3
     monkeypatch.delenv("STV_IMAGES_PER_GPU")
-    assert parallel.images_in_flight(10) == (2 if torch.cuda.is_available() else 1)
+    assert parallel.images_in_flight(10) == (3 if torch.cuda.is_available() else 1)
