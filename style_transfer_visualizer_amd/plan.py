@@ -369,8 +369,9 @@ class Schedule:
         if not todo:
             return
         chain = all(nd.src is self.nodes[i - 1].dst for i, nd in enumerate(self.nodes) if i > 0)
-        arena = (os.environ.get("STV_GRAD_ARENA", "1") != "0" and not self.halo and chain and len(todo) == len(self.nodes)
-                 and all(nd.dst.act.is_cuda for nd in self.nodes))
+        mode = os.environ.get("STV_GRAD_ARENA", "1")          # "2": also for host tensors (the host tests walk the allocator)
+        arena = (mode != "0" and not self.halo and chain and len(todo) == len(self.nodes)
+                 and (mode == "2" or all(nd.dst.act.is_cuda for nd in self.nodes)))
         if not arena:
             for nd in todo:              # strips: halo rows are read before anything wrote them -> start finite
                 nd.dst.grad = torch.zeros_like(nd.dst.act) if self.halo else torch.empty_like(nd.dst.act)

@@ -309,3 +309,43 @@ def test_cache_notice_when_the_checkpoint_is_present(monkeypatch, tmp_path, capl
     caplog.set_level(logging.INFO, logger="style_transfer")
     core_model.initialize_vgg()
     assert any("Using cached VGG19 weights" in m and str(cached) in m for m in caplog.messages)
+
+
+@pytest.mark.parametrize("style_at,content_at", [([0, 5, 10, 19, 28], [21]), ([0, 5, 10, 19, 28], [7]), ([2, 7], [16, 25]), ([28], [0])])
+def test_gradient_slabs_follow_the_reverse_schedule(style_at, content_at, monkeypatch):
+    """plan.alloc_grads hands the gradients of the reverse chain a few rotating slabs (STV_GRAD_ARENA=2: also for host
+    tensors).  Invariants, for several tap layouts (content tap in the middle, on a layer in front of a pool, on the very first
+    conv; taps on conv / ReLU / pool outputs): buffers with a content tap keep a tensor of their own; two gradients one
+    op reads and writes never share a slab; `backward_ops` itself re-checks op by op that every reader finds its writer's
+    data (it raises otherwise); the per-node form gives the same op list."""
+    def build(arena):
+        monkeypatch.setenv("STV_GRAD_ARENA", arena)
+        s = plan.Schedule(_layers(), style_at, content_at, 32, 32, torch.float32, CPU, with_grad=True)
+        for tap in s.style_taps:
+            tap.sgrad = torch.zeros(1, tap.buf.C, tap.buf.C)
+        for tap in s.content_taps:
+            tap.target = torch.zeros_like(tap.buf.act)
+        ops_ = s.backward_ops(torch.zeros(1, 3, 32, 32), style_coef=1.0, content_coef=1.0, coef_dev=None)
+        return s, ops_
+    s, ops_a = build("2")
+    s0, ops_0 = build("0")
+    assert [(o.op, o.H, o.W, o.cin, o.cout, o.taps, o.flags) for o in ops_a] == [(o.op, o.H, o.W, o.cin, o.cout, o.taps, o.flags) for o in ops_0]
+    slabs, slab_of = s._grad_slabs, s._grad_slab_of
+    assert 1 <= slabs.shape[0] <= 3
+    base = slabs.untyped_storage().data_ptr()
+    own = {id(t.buf) for t in s.content_taps}
+    for i, nd in enumerate(s.nodes):
+        b = nd.dst
+        assert b.grad.shape == b.act.shape and b.grad.dtype == b.act.dtype
+        if id(b) in own:
+            assert b.grad.untyped_storage().data_ptr() != base and id(b) not in slab_of
+        else:
+            assert b.grad.untyped_storage().data_ptr() == base
+            assert b.grad.data_ptr() == slabs[slab_of[id(b)]].data_ptr()
+        if i > 0 and id(b) in slab_of and id(nd.src) in slab_of:      # the op of node i reads b's gradient and writes src's
+            assert slab_of[id(b)] != slab_of[id(nd.src)]
+    per_node = sum(nd.dst.act.numel() * 4 for nd in s0.nodes)
+    assert slabs.numel() < per_node
+    # a second build of the reverse schedule (the autograd path builds its own program) reuses the assignment
+    again = s.backward_ops(torch.zeros(1, 3, 32, 32), style_coef=1.0, content_coef=1.0, coef_dev=None)
+    assert len(again) == len(ops_a) and s._grad_slabs is slabs
