@@ -297,6 +297,7 @@ def run_gpu(args, rank: int, world: int, device: torch.device, size: int, steps:
         info["roofline"] = {
             "bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": peak,
             "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "traffic_meaning": "fabric bytes incl. Infinity-Cache hits (FETCH_SIZE x2 + WRITE_SIZE, per launch): L2 fills and write-backs, an upper bound on HBM bytes",
             "launches_per_step": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 5),
             "avg_launch_ms_cache_hot": round(dom["ms_hot"] / dom["launches"], 5),
             "flop_per_launch": dom["flops"] / dom["launches"],
@@ -681,8 +682,9 @@ def main() -> None:
                 "timed_region": "exactly --steps optimizer steps at a full L-BFGS history (m = 100), after --warmup untimed ones",
                 "world_size": world,
                 "per_rank_elapsed_s": per_rank,
-                "collectives": (f"RCCL {_rccl_version()} (torch.distributed backend "
-                                f"'{args.dist_backend}'): one all-gather of the final images after the timed region") if world > 1 else None,
+                "collectives": ((f"RCCL {_rccl_version()} (torch.distributed backend 'nccl')" if args.dist_backend == "nccl"
+                                 else f"{args.dist_backend} (rehearsal: ranks share one GPU, RCCL not used)")
+                                + ": one all-gather of the final images after the timed region") if world > 1 else None,
                 "single_gpu_reference": ("this line's workload at N = 1 is `extra_1024.value` / `roofline.step_1024.steps_per_s` of the "
                                          "`--gpus 1` line (whose headline is configs[1], 512x512)") if world > 1 and head_size == 1024 else None,
             },

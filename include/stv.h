@@ -61,9 +61,10 @@ int stv_gram_ksplit(int n_pixels, int channels);
  *      `x = block(x)` (core_model.py:316) and their autograd backward
  *      (`loss.backward()`, optimization.py:313). ---------------------------- */
 
-/* (The two unpacked entries below repack `wf` into one process-wide scratch buffer on
- * every call: they are meant for single-stream use - tests, one-off calls.  Concurrent
- * streams and the step path use stv_conv_first_pack + the *_packed entries further down.) */
+/* (The two unpacked entries below read `wf` as it is, with the shape-generic first-layer
+ * kernels; the library holds no scratch of its own.  The 3 -> 64 layer's fast kernels need the
+ * kernel-side weight order: stv_conv_first_pack + the *_packed entries further down, which is
+ * what the step path and ops.py use.) */
 /* First conv: NCHW fp32 image [cin][H][W] -> NHWC `dtype` [H][W][cout].
  * wf is [9][cout][cin] fp32 (tap = ky*3+kx), bias fp32[cout]. */
 int stv_conv_first_fwd(const float* x_nchw, const float* wf, const float* bias,

@@ -119,16 +119,71 @@ def per_step_sensitivity(weights, cfg, content, style, x0, *, style_layers, cont
     return out
 
 
+def trajectory_spread(weights, cfg, content, style, x0, *, style_layers, content_layers, style_w,
+                      content_w, steps, optimizer, adam_lr, eps=3e-7):
+    """The two measures above plus the spread of the LOGGED LOSSES, from one set of seven oracle runs (the large
+    fixtures: a run is minutes).  Returns (x_final sensitivity, per-step image sensitivity [steps], per-step
+    relative loss spread [steps, 3] in the order style / content / total)."""
+    model = ocm.OracleModel(ocm.vgg_program(weights, cfg), style_layers, content_layers)
+    model.set_targets(style, content)
+
+    def run(seed, elementwise=False):
+        gen = torch.Generator().manual_seed(seed)
+
+        def lg(x):
+            s, c, t, g = ocm.loss_and_grad(model, x, style_w, content_w)
+            if seed and elementwise:
+                g = g * (1 + eps * torch.randn(g.shape, generator=gen))
+            elif seed:
+                g = g * (1 + eps * float(torch.randn((), generator=gen)))
+            return s, c, t, g
+        res = optim_ref.run_loop(lg, x0, steps, optimizer=optimizer, lr=adam_lr if optimizer == "adam" else None,
+                                 keep_steps=True)
+        h = res["history"]
+        return res["x_steps"], np.stack([np.asarray(h["style"]), np.asarray(h["content"]), np.asarray(h["total"])], axis=1)
+    base_x, base_l = run(0)
+    x_sens, l_sens = np.zeros(steps), np.zeros((steps, 3))
+    for s in (1, 2, 3):
+        for ew in (False, True):
+            xs, ls = run(s, ew)
+            for k, (a, b) in enumerate(zip(xs, base_x, strict=True)):
+                scale = float(b.abs().max())
+                dev = float((a - b).abs().max()) / scale if np.isfinite(scale) and scale > 0 else float("nan")
+                x_sens[k] = max(x_sens[k], dev) if np.isfinite(dev) else float("nan")
+            with np.errstate(divide="ignore", invalid="ignore"):
+                rel = np.abs(ls - base_l) / np.abs(base_l)
+            rel[~np.isfinite(rel)] = 0.0          # a loss that is exactly zero in both runs (content start, step 1)
+            l_sens = np.maximum(l_sens, rel)
+    return float(x_sens[-1]), x_sens, l_sens
+
+
+def png_roundtrip(seed, h, w, *, normalize):
+    """The tensor ``image_io.load_image_to_tensor`` gives for the PNG the config tests write from the synthetic
+    image: uint8 quantisation (``mul(255).byte()``), ``ToTensor`` (``/255``) and ``Normalize`` (reference
+    image_io.py:72-84)."""
+    u8 = synthetic.synthetic_image(seed, h, w, normalize=False)[0].mul(255).byte()
+    t = u8.to(torch.float32).div(255)
+    if normalize:
+        mean = torch.tensor([0.485, 0.456, 0.406], dtype=torch.float32).view(3, 1, 1)
+        std = torch.tensor([0.229, 0.224, 0.225], dtype=torch.float32).view(3, 1, 1)
+        t = (t - mean) / std
+    return t.unsqueeze(0)
+
+
 def run_case(ref, name, *, cfg, cfg_name, wseed, hw_content, hw_style, style_layers,
              content_layers, init_method, steps, optimizer, style_w=1e5, content_w=1.0,
              gain_first=1.0, bias_scale=0.0, normalize=True, adam_lr=1e-3,
-             subsample_targets=False, store_steps=False):
+             subsample_targets=False, store_steps=False, png_inputs=False, compact=0, log_every=2):
     ref_core, ref_opt, ref_config, _ = ref
     weights = _weights(cfg, wseed, gain_first, bias_scale)
     ref_core.initialize_vgg = lambda: ref_harness.build_sequential(weights, cfg)
 
-    content = synthetic.synthetic_image(0, *hw_content, normalize=normalize)
-    style = synthetic.synthetic_image(1, *hw_style, normalize=normalize)
+    if png_inputs:
+        content = png_roundtrip(0, *hw_content, normalize=normalize)
+        style = png_roundtrip(1, *hw_style, normalize=normalize)
+    else:
+        content = synthetic.synthetic_image(0, *hw_content, normalize=normalize)
+        style = synthetic.synthetic_image(1, *hw_style, normalize=normalize)
 
     config = ref_config.StyleTransferConfig.model_validate({})
     oc = config.optimization
@@ -141,7 +196,7 @@ def run_case(ref, name, *, cfg, cfg_name, wseed, hw_content, hw_style, style_lay
     oc.normalize = normalize
     config.video.create_video = False
     config.video.final_only = True
-    config.output.log_every = 2
+    config.output.log_every = log_every
 
     torch.manual_seed(0)
     model, input_img, lbfgs = ref_core.prepare_model_and_input(
@@ -156,6 +211,7 @@ def run_case(ref, name, *, cfg, cfg_name, wseed, hw_content, hw_style, style_lay
     grads = {}
     logged = []
     x_steps = []
+    states = []
 
     def on_end(metrics):
         if metrics.step == 1:
@@ -163,6 +219,9 @@ def run_case(ref, name, *, cfg, cfg_name, wseed, hw_content, hw_style, style_lay
         logged.append((metrics.step, metrics.has_values))
         if store_steps:
             x_steps.append(input_img.detach().clone().numpy())
+        if compact and optimizer == "lbfgs":          # torch.optim.LBFGS keeps its state under its first parameter
+            st = opt.state[opt._params[0]]
+            states.append((int(st.get("n_iter", 0)), len(st.get("old_dirs") or [])))
 
     runner = ref_opt.OptimizationRunner(
         model, input_img, config, optimizer=opt, progress_bar=_Bar(),
@@ -180,14 +239,9 @@ def run_case(ref, name, *, cfg, cfg_name, wseed, hw_content, hw_style, style_lay
                 f = x.reshape(b * c, h * w)
                 hits.append(int((torch.mm(f, f.t()) > 5e5).sum()))
 
-    sens = trajectory_sensitivity(weights, cfg, content, style, x0, style_layers=style_layers,
-                                  content_layers=content_layers, style_w=style_w, content_w=content_w,
-                                  steps=steps, optimizer=optimizer, adam_lr=adam_lr)
+    spread_kw = dict(style_layers=style_layers, content_layers=content_layers, style_w=style_w, content_w=content_w,
+                     steps=steps, optimizer=optimizer, adam_lr=adam_lr)
     arrays = {
-        "x_final_sensitivity": np.asarray(sens, dtype=np.float64),
-        "x0": x0.numpy(),
-        "x_final": out_img.detach().numpy(),
-        "grad_step1": grads["g1"].numpy(),
         "style_loss": np.asarray(history["style_loss"], dtype=np.float64),
         "content_loss": np.asarray(history["content_loss"], dtype=np.float64),
         "total_loss": np.asarray(history["total_loss"], dtype=np.float64),
@@ -195,13 +249,43 @@ def run_case(ref, name, *, cfg, cfg_name, wseed, hw_content, hw_style, style_lay
         "closure_calls": np.asarray(runner._closure_calls, dtype=np.int64),
         "logged_steps": np.asarray([s for s, has in logged if has], dtype=np.int64),
     }
-    if store_steps:
-        # the image after every step: a trajectory that overshoots (L-BFGS without line search can) is
-        # compared at the last step whose loss is still comparable, not only at the end
-        arrays["x_steps"] = np.stack(x_steps)
-        arrays["x_steps_sensitivity"] = per_step_sensitivity(
-            weights, cfg, content, style, x0, style_layers=style_layers, content_layers=content_layers,
-            style_w=style_w, content_w=content_w, steps=steps, optimizer=optimizer, adam_lr=adam_lr)
+    if compact:
+        # the large fixtures: images subsampled (every `compact`-th row and column) + float64 checksums of the whole
+        k = compact
+        sens, x_sens, l_sens = trajectory_spread(weights, cfg, content, style, x0, **spread_kw)
+        xf, g1 = out_img.detach().numpy(), grads["g1"].numpy()
+        arrays.update({
+            "x_final_sensitivity": np.asarray(sens, dtype=np.float64),
+            "x_steps_sensitivity": x_sens, "loss_sensitivity": l_sens,
+            "x_final_sub": xf[..., ::k, ::k].copy(), "x_final_sum": np.asarray(xf.astype(np.float64).sum()),
+            "x_final_abs_sum": np.asarray(np.abs(xf.astype(np.float64)).sum()), "x_final_absmax": np.asarray(np.abs(xf).max()),
+            "grad_step1_sub": g1[..., ::k, ::k].copy(), "grad_step1_abs_sum": np.asarray(np.abs(g1.astype(np.float64)).sum()),
+            "grad_step1_absmax": np.asarray(np.abs(g1).max()),
+            "x0_abs_sum": np.asarray(np.abs(x0.numpy().astype(np.float64)).sum()),
+            "x0_is_content": np.asarray(bool(torch.equal(x0, content))),
+        })
+        if not torch.equal(x0, content):
+            arrays["x0"] = x0.numpy()
+        if states:
+            arrays["lbfgs_state"] = np.asarray(states, dtype=np.int64)          # (n_iter, history length) after every step
+        if store_steps:
+            xs = np.stack(x_steps)
+            arrays["x_steps_sub"] = xs[..., ::k, ::k].copy()
+            arrays["x_steps_abs_sum"] = np.abs(xs.astype(np.float64)).sum(axis=(1, 2, 3, 4))
+            arrays["x_steps_absmax"] = np.abs(xs).max(axis=(1, 2, 3, 4))
+    else:
+        sens = trajectory_sensitivity(weights, cfg, content, style, x0, **spread_kw)
+        arrays.update({
+            "x_final_sensitivity": np.asarray(sens, dtype=np.float64),
+            "x0": x0.numpy(),
+            "x_final": out_img.detach().numpy(),
+            "grad_step1": grads["g1"].numpy(),
+        })
+        if store_steps:
+            # the image after every step: a trajectory that overshoots (L-BFGS without line search can) is
+            # compared at the last step whose loss is still comparable, not only at the end
+            arrays["x_steps"] = np.stack(x_steps)
+            arrays["x_steps_sensitivity"] = per_step_sensitivity(weights, cfg, content, style, x0, **spread_kw)
     for i, t in enumerate(model.style_targets):
         a = t.numpy()
         if subsample_targets and a.shape[0] > 128:
@@ -219,7 +303,7 @@ def run_case(ref, name, *, cfg, cfg_name, wseed, hw_content, hw_style, style_lay
         style_layers=list(style_layers), content_layers=list(content_layers),
         init_method=init_method, steps=steps, optimizer=optimizer, style_w=style_w,
         content_w=content_w, gain_first=gain_first, bias_scale=bias_scale,
-        normalize=normalize, adam_lr=adam_lr,
+        normalize=normalize, adam_lr=adam_lr, png_inputs=png_inputs, compact=compact, log_every=log_every,
         block_count=len(model.vgg_blocks), style_ids=list(model.style_ids),
         content_ids=list(model.content_ids),
         torch_version=torch.__version__,
@@ -263,40 +347,59 @@ def gram_kats(ref):
     print("gram_kats:", out["kat1_out"].tolist(), out["kat2_out_clamp30"].tolist())
 
 
-def main():
+def main(argv=None):
+    """``python -m oracle.make_golden [name ...]``: all fixtures, or only the named ones."""
+    only = set(sys.argv[1:] if argv is None else argv)
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     torch.set_num_threads(8)
     ref = ref_harness.import_reference()
-    gram_kats(ref)
+
+    def case(name, **kw):
+        if not only or name in only:
+            run_case(ref, name, **kw)
+    if not only or "gram_kats" in only:
+        gram_kats(ref)
     S, C = (0, 5, 10, 19, 28), (21,)
     common = dict(cfg=MINI_CFG, cfg_name="mini", wseed=3, hw_content=(64, 64), hw_style=(80, 64),
                   style_layers=S, content_layers=C)
-    run_case(ref, "mini_white_lbfgs", init_method="white", steps=6, optimizer="lbfgs", **common)
-    run_case(ref, "mini_content_lbfgs", init_method="content", steps=6, optimizer="lbfgs",
+    case("mini_white_lbfgs", init_method="white", steps=6, optimizer="lbfgs", **common)
+    case("mini_content_lbfgs", init_method="content", steps=6, optimizer="lbfgs",
              style_w=1e7, **common)
-    run_case(ref, "mini_random_lbfgs_nonorm", init_method="random", steps=5, optimizer="lbfgs",
+    case("mini_random_lbfgs_nonorm", init_method="random", steps=5, optimizer="lbfgs",
              normalize=False, bias_scale=0.05, **common)
-    run_case(ref, "mini_white_adam", init_method="white", steps=5, optimizer="adam", adam_lr=1e-2, **common)
-    run_case(ref, "mini_clamp_lbfgs", init_method="white", steps=4, optimizer="lbfgs",
+    case("mini_white_adam", init_method="white", steps=5, optimizer="adam", adam_lr=1e-2, **common)
+    case("mini_clamp_lbfgs", init_method="white", steps=4, optimizer="lbfgs",
              gain_first=12.0, store_steps=True, **common)
-    run_case(ref, "mini_clamp_adam", init_method="white", steps=5, optimizer="adam", adam_lr=1e-2,
+    case("mini_clamp_adam", init_method="white", steps=5, optimizer="adam", adam_lr=1e-2,
              gain_first=12.0, **common)
-    run_case(ref, "tiny_taps_lbfgs", cfg=TINY_CFG, cfg_name="tiny", wseed=5, hw_content=(16, 16),
+    case("tiny_taps_lbfgs", cfg=TINY_CFG, cfg_name="tiny", wseed=5, hw_content=(16, 16),
              hw_style=(16, 24), style_layers=(0, 2, 4), content_layers=(1, 3),
              init_method="white", steps=4, optimizer="lbfgs", bias_scale=0.1, store_steps=True)
-    run_case(ref, "vgg19_white_lbfgs", cfg=synthetic.VGG19_CFG, cfg_name="vgg19", wseed=0,
+    case("vgg19_white_lbfgs", cfg=synthetic.VGG19_CFG, cfg_name="vgg19", wseed=0,
              hw_content=(64, 64), hw_style=(64, 96), style_layers=S, content_layers=C,
              init_method="white", steps=3, optimizer="lbfgs", subsample_targets=True, store_steps=True)
     # full width, NOT chaotic (measured sensitivity 2e-7): the fixture that must meet north_star's 1e-4 per
     # pixel outright.  (Adam from the white image is not such a case - sensitivity 3e-3: Adam moves a pixel
     # by ~lr whatever the size of its gradient, and the white image has many near-zero gradient entries whose
     # sign is rounding noise; from the random start image - the reference's default init - every entry is large.)
-    run_case(ref, "vgg19_random_adam", cfg=synthetic.VGG19_CFG, cfg_name="vgg19", wseed=0,
+    case("vgg19_random_adam", cfg=synthetic.VGG19_CFG, cfg_name="vgg19", wseed=0,
              hw_content=(64, 64), hw_style=(64, 96), style_layers=S, content_layers=C,
              init_method="random", steps=4, optimizer="adam", adam_lr=1e-2, subsample_targets=True)
-    run_case(ref, "vgg19_content_lbfgs", cfg=synthetic.VGG19_CFG, cfg_name="vgg19", wseed=0,
+    case("vgg19_content_lbfgs", cfg=synthetic.VGG19_CFG, cfg_name="vgg19", wseed=0,
              hw_content=(64, 64), hw_style=(64, 96), style_layers=S, content_layers=C,
              init_method="content", steps=4, optimizer="lbfgs", style_w=1e8, subsample_targets=True)
+
+    # ---- the two LARGE fixtures (VERDICT r4 item 4): minutes each, images stored subsampled + float64 checksums --------
+    # BASELINE.json configs[0] as the reference runs it: 256x256, --init content, 50 L-BFGS steps, default layers and
+    # weights, log_every 10 (the reference's default); inputs as its image loader returns them for the 8-bit PNGs of the
+    # synthetic images (what the config tests feed ``cli.main``).
+    case("cfg0_256_content_lbfgs50", cfg=synthetic.VGG19_CFG, cfg_name="vgg19", wseed=0, hw_content=(256, 256),
+         hw_style=(256, 256), style_layers=S, content_layers=C, init_method="content", steps=50, optimizer="lbfgs",
+         subsample_targets=True, png_inputs=True, compact=4, log_every=10)
+    # full width, the reference's default start (random), 12 L-BFGS steps at 128x128: the image after every step
+    case("vgg19_128_random_lbfgs12", cfg=synthetic.VGG19_CFG, cfg_name="vgg19", wseed=0, hw_content=(128, 128),
+         hw_style=(128, 160), style_layers=S, content_layers=C, init_method="random", steps=12, optimizer="lbfgs",
+         subsample_targets=True, store_steps=True, compact=2)
 
 
 if __name__ == "__main__":

@@ -162,6 +162,7 @@ def run_loop(
     optimizer: str = "lbfgs",
     lr: float | None = None,
     keep_steps: bool = False,
+    on_step: Callable | None = None,
 ) -> dict:
     """Step loop with the reference's accounting (optimization.py:162-202).
 
@@ -196,4 +197,6 @@ def run_loop(
         hist["total"].append(rec["t"])
         if keep_steps:
             x_steps.append(x.detach().clone())
+        if on_step is not None:
+            on_step(opt)
     return {"x": x, "history": hist, "first_grad": first_grad, "optimizer": opt, "x_steps": x_steps}

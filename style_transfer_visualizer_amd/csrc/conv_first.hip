@@ -673,16 +673,9 @@ inline int lanes_shift(int cout, int kvec) {
   return s;
 }
 
-// scratch for the repacked first-layer weights (2 x 1728 floats) of callers that did not pre-pack them
-// (stv_conv_first_pack), allocated once per HOST THREAD: several images may be in flight in one process, each driven
-// by its own thread on its own stream, and a repack on one stream must not overwrite what a conv on another reads
-float* first_scratch() {
-  thread_local float* p = nullptr;
-  if (!p && hipMalloc(reinterpret_cast<void**>(&p), 2 * 1728 * sizeof(float)) != hipSuccess) p = nullptr;
-  return p;
-}
-
-// `packed` (optional): the caller's buffer from stv_conv_first_pack - no per-call repack
+// `packed` (optional): the caller's buffer from stv_conv_first_pack.  The 3 -> 64 kernels read the weights in their
+// kernel-side order only; a caller without that buffer gets the shape-generic kernels below, which read `wf` as it is
+// (the library keeps no scratch of its own: nothing hidden is shared between streams, threads or devices).
 template <typename T>
 int fwd_typed(const float* x, const float* wf, const float* packed, const float* bias, void* y, int H, int W,
               int cin, int cout, hipStream_t st, float* gram_slabs = nullptr) {
@@ -701,14 +694,8 @@ int fwd_typed(const float* x, const float* wf, const float* packed, const float*
     return STV_OK;
   }
   if (gram_slabs) return STV_ERR_ARG;
-  if (cin == 3 && cout == 64) {
+  if (cin == 3 && cout == 64 && packed) {
     const float* wt = packed;
-    if (!wt) {
-      float* scratch = first_scratch();
-      if (!scratch) return STV_ERR_ALLOC;
-      hipLaunchKernelGGL(repack_first_weights, dim3(7), dim3(256), 0, st, wf, scratch, 0);
-      wt = scratch;
-    }
     const int tiles = ceil_div(W, FT) * ceil_div(H, FT);
     hipLaunchKernelGGL(conv_first_fwd_c64<T>, dim3(tiles), dim3(256), 0, st, x, wt, bias, static_cast<T*>(y), H, W);
     STV_CHECK_LAUNCH();
@@ -741,14 +728,8 @@ int dgrad_typed(const void* dy, const float* wf, const float* packed, float* dx,
     STV_CHECK_LAUNCH();
     return STV_OK;
   }
-  if (cin == 3 && cout == 64) {
-    const float* wd = packed ? packed + 1728 : nullptr;
-    if (!wd) {
-      float* scratch = first_scratch();
-      if (!scratch) return STV_ERR_ALLOC;
-      hipLaunchKernelGGL(repack_first_weights, dim3(7), dim3(256), 0, st, wf, scratch + 1728, 1);
-      wd = scratch + 1728;
-    }
+  if (cin == 3 && cout == 64 && packed) {
+    const float* wd = packed + 1728;
     const int tiles = ceil_div(W, FT) * ceil_div(H, FT);
     const size_t lds = (size_t)FH * FH * (64 * sizeof(T) + 16);
     if (stv_set_max_lds(reinterpret_cast<const void*>(&conv_first_dgrad_c64<T>), (int)lds) != STV_OK) return STV_ERR_LAUNCH;

@@ -431,6 +431,7 @@ extern "C" int stv_conv_igemm(const void* x, const void* w, const float* bias, c
                               int dtype, void* stream) {
   if (!x || !w || !y || H <= 0 || W <= 0 || cin <= 0 || cout <= 0) return STV_ERR_ARG;
   if ((flags & STV_MASK) && !ref) return STV_ERR_ARG;
+  if (flags & STV_POOL_ONLY) return STV_ERR_ARG;          // only stv_conv_igemm_pool has a pooled map to write instead of y
   if (taps != 9 && taps != 1) return STV_ERR_ARG;
   // the direct fallback (shapes the matrix-core tiling does not cover) reads plain weights only
   if ((flags & STV_W_BLOCKED) && choose_cfg(H, W, cin, cout, dtype == STV_F32 ? 4 : 2, taps) < 0) return STV_ERR_ARG;
@@ -470,7 +471,7 @@ extern "C" int stv_conv_igemm_route(const void* x, const void* w, const void* po
                                     int cout, int flags, int dtype, void* stream) {
   if (!x || !w || !pool_idx || !y_full || H <= 0 || W <= 0 || cin <= 0 || cout <= 0) return STV_ERR_ARG;
   if (dtype != STV_BF16) return STV_ERR_ARG;                                   // packed-word routing: bf16 storage only
-  if (flags & (STV_RELU_IN | STV_RELU_OUT | STV_ACCUM)) return STV_ERR_ARG;
+  if (flags & (STV_RELU_IN | STV_RELU_OUT | STV_ACCUM | STV_POOL_ONLY)) return STV_ERR_ARG;
   // 32-bit buffer offsets: the input (H x W x cin) and the routed output (2H x 2W x cout), bf16
   if ((size_t)H * W * (size_t)cin * 2 >= (size_t)1 << 31 || (size_t)4 * H * W * (size_t)cout * 2 >= (size_t)1 << 31) return STV_ERR_ARG;
   if (choose_cfg(H, W, cin, cout, 2, kRouteTaps) < 0) return STV_ERR_ARG;
@@ -487,7 +488,7 @@ extern "C" int stv_conv_igemm_dual(const void* x, const void* w, const void* x2,
                                    void* stream) {
   if (!x || !w || !x2 || !w2 || !y || H <= 0 || W <= 0 || cin <= 0 || cin2 <= 0 || cout <= 0) return STV_ERR_ARG;
   if ((flags & STV_MASK) && !ref) return STV_ERR_ARG;
-  if (flags & (STV_RELU_IN | STV_RELU_OUT)) return STV_ERR_ARG;             // a gradient path: no activations
+  if (flags & (STV_RELU_IN | STV_RELU_OUT | STV_POOL_ONLY)) return STV_ERR_ARG;   // a gradient path: no activations, no pooled output
   if (dtype != STV_F32 && dtype != STV_BF16) return STV_ERR_ARG;
   const size_t cmax = (size_t)(cin > cout ? cin : cout) > (size_t)cin2 ? (size_t)(cin > cout ? cin : cout) : (size_t)cin2;
   if ((size_t)H * W * cmax >= (size_t)1 << 31) return STV_ERR_ARG;

@@ -867,7 +867,9 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
       if (STV_DIAG & 2) return kOob;                   // (timing knock-out: no output stores)
       return (gy < a.H && gx < a.W) ? (uint32_t)(((gy * a.W + gx) * a.cout) * (int)sizeof(T)) : kOob;
     };
-    if (!(a.flags & STV_POOL_ONLY))      // (pooling launches whose full-resolution map nobody reads: stv.h)
+    // (pooling launches whose full-resolution map nobody reads, stv.h - honoured only where this tile really writes the
+    //  pooled map instead: a pooled output is given and a wave owns both rows of a window)
+    if (!((a.flags & STV_POOL_ONLY) && a.pool != nullptr && C::MT % 2 == 0))
       emit([&](int mt, int nt, int i) { return acc[mt][nt][i]; }, full_off, rs_y, C::MT, do_mask, do_acc);
 
     // Fused MaxPool2d(2,2) (forward convs in front of a pool): the vertical pair of a window is
@@ -948,9 +950,13 @@ int launch_cfg(const ConvArgs& a_in, hipStream_t st) {
   g_stv_next_w = nullptr;          // one shot: the hint belongs to THIS launch, whatever launches next on the thread starts without one
   g_stv_next_w_bytes = 0;
   {
-    // XCDs per spatial tile (ConvArgs::xshare).  STV_CONV_XSHARE: 1 / 2 / 4 forces it; default: the weights of one
-    // workgroup generation's channel blocks should fit an XCD's 4-MB L2 beside the input tiles
-    static const int forced = getenv("STV_CONV_XSHARE") ? atoi(getenv("STV_CONV_XSHARE")) : 0;
+    // XCDs a spatial tile's channel blocks are dealt to (ConvArgs::xshare).  Always 1 unless STV_CONV_XSHARE = 2 / 4
+    // asks for more: measured 0.6-1.3 % slower in the step (DESIGN.md 3.8 - the weight fills it saves come out of the
+    // Infinity Cache and nobody waits for them), so there is no heuristic; the switch and the block decode stay for
+    // A/B runs and are covered by tests/test_gpu_ops.py::test_conv_xshare_changes_nothing.  Read per launch (launches
+    // are captured into the step's graph once), so a test can flip it inside one process.
+    const char* xs = getenv("STV_CONV_XSHARE");
+    const int forced = xs ? atoi(xs) : 0;
     const int ny = ceil_div(a.cout, C::BN);
     int g = forced > 0 ? forced : 1;
     if (g != 1 && g != 2 && g != 4) g = 1;

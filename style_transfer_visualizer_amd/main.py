@@ -21,8 +21,12 @@ from .type_defs import InputPaths, SaveOptions
 _SETUP_LOCK = threading.Lock()
 
 
-def style_transfer(paths: InputPaths, config, *, video_writer=None, gif_collector=None) -> torch.Tensor:
-    """Run one style transfer; returns the optimised image clamped to [0, 1]."""
+def style_transfer(paths: InputPaths, config, *, video_writer=None, gif_collector=None, output_tag: str = "",
+                   tag_png: bool = True) -> torch.Tensor:
+    """Run one style transfer; returns the optimised image clamped to [0, 1].
+
+    ``output_tag`` (``style_transfer_batch``): appended to the names of this run's loss CSV and loss plot - and, with
+    ``tag_png``, of its PNG - so that several runs writing into one directory do not overwrite each other."""
     runtime.validate_input_paths(paths.content_path, paths.style_path)
     runtime.validate_parameters(config.video.quality)
 
@@ -46,7 +50,10 @@ def style_transfer(paths: InputPaths, config, *, video_writer=None, gif_collecto
             content_img, style_img, device, config.optimization, precision=config.hardware.precision)
 
     output_path = runtime.setup_output_directory(config.output.output)
-    content_name, style_name = Path(paths.content_path).stem, Path(paths.style_path).stem
+    content_name, style_name = Path(paths.content_path).stem, Path(paths.style_path).stem + (output_tag if tag_png else "")
+    if output_tag and config.output.log_loss:
+        log_path = Path(config.output.log_loss)
+        config.output.log_loss = str(log_path.with_name(log_path.stem + output_tag + log_path.suffix))
 
     runner = optimization.OptimizationRunner(model, input_img, config, optimizer=optimizer,
                                              video_writer=video_writer, gif_collector=gif_collector)
@@ -58,7 +65,8 @@ def style_transfer(paths: InputPaths, config, *, video_writer=None, gif_collecto
     runtime.save_outputs(input_img, loss_metrics, output_path, elapsed, SaveOptions(
         content_name=content_name, style_name=style_name, normalize=normalize,
         video_created=video_writer is not None, gif_created=gif_collector is not None,
-        plot_losses=config.output.plot_losses))
+        plot_losses=config.output.plot_losses),
+        **({"plot_name": f"loss_plot{output_tag}.png"} if output_tag else {}))      # (untagged: the reference's call, runtime/output.py:55)
     return input_img.detach().clamp(0, 1)
 
 
@@ -69,8 +77,11 @@ def style_transfer_batch(pairs: list[InputPaths], config, *, images_per_gpu: int
     core_model.py:56-57) - but N replicas of the single-image path: rank r runs pairs r, r + world, ...
     each with its own model targets and L-BFGS state, writes their PNGs, and one all-gather at the end
     hands every rank the full ordered list of result images (they must share one size).
-    ``images_per_gpu`` of a rank's pairs run at the same time, each on its own stream (default 3:
-    ``parallel.images_in_flight``) - same results, one image's optimizer update overlaps another's closure.
+    ``images_per_gpu`` of a rank's pairs run at the same time, each on its own stream (opt-in: default 1, or
+    ``STV_IMAGES_PER_GPU``; ``parallel.images_in_flight``) - same results, one image's optimizer update overlaps
+    another's closure, at that many times the device memory.  Every pair works on its own copy of ``config``; with
+    more than one pair the loss CSV (``output.log_loss``) and the loss plot carry the pair's index, and so does the PNG
+    of a pair whose content/style names occur more than once in ``pairs`` - no two pairs write one file.
     """
     import copy  # noqa: PLC0415
 
@@ -80,6 +91,10 @@ def style_transfer_batch(pairs: list[InputPaths], config, *, images_per_gpu: int
     if torch.cuda.is_available():              # "cuda" in the config then means this rank's GPU
         torch.cuda.set_device(local_rank % torch.cuda.device_count())
 
-    def one(_index: int, paths: InputPaths) -> torch.Tensor:
-        return style_transfer(paths, copy.deepcopy(config)).contiguous()
+    stems = [(Path(p.content_path).stem, Path(p.style_path).stem) for p in pairs]
+
+    def one(index: int, paths: InputPaths) -> torch.Tensor:
+        tag = f"_{index:03d}" if len(pairs) > 1 else ""
+        # (a pair whose names are unique in the batch keeps the reference's PNG name, runtime/output.py:46-52)
+        return style_transfer(paths, copy.deepcopy(config), output_tag=tag, tag_png=stems.count(stems[index]) > 1).contiguous()
     return parallel.run_sharded(list(pairs), one, concurrent=images_per_gpu)

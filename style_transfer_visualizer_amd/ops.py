@@ -125,6 +125,8 @@ def conv_first_fwd(x_nchw: torch.Tensor, wf: torch.Tensor, bias: torch.Tensor | 
     ([gram_ksplit(H*W, cout), cout, cout] fp32; needs ``packed``): also filled, as :func:`gram_partial` of the result would."""
     _, cin, H, W = x_nchw.shape
     cout = wf.shape[1]
+    if packed is None and gram_partials is None and (cin, cout) == (3, 64):
+        packed = conv_first_pack(wf)      # the 3 -> 64 kernels read the kernel-side order (a torch-owned buffer, this stream)
     if out is None:
         out = torch.empty(H, W, cout, device=x_nchw.device, dtype=dtype)
     lib = _lib.load()
@@ -148,6 +150,8 @@ def conv_first_dgrad(dy: torch.Tensor, wf: torch.Tensor, cin: int,
     if out is None:
         out = torch.empty(1, cin, H, W, device=dy.device, dtype=torch.float32)
     lib = _lib.load()
+    if packed is None and (cin, cout) == (3, 64):
+        packed = conv_first_pack(wf)
     if packed is not None:
         _lib.check(lib.stv_conv_first_dgrad_packed(_ptr(dy), _ptr(packed), _ptr(out), H, W, cin, cout,
                                                    dtype_code(dy.dtype), _stream()), "stv_conv_first_dgrad_packed")

@@ -93,10 +93,12 @@ def images_in_flight(n_local: int, requested: int | None = None) -> int:
     One image leaves the GPU half idle in two different ways - its closure is bound by the matrix cores and their
     instruction issue, its L-BFGS update by HBM - so two or three independent images on one GPU overlap one's update
     with another's closure: `tools/two_images_probe.py`, one MI355X, aggregate steps/s by images in flight 1 / 2 / 3 / 4: 256^2 2,172 / 3,079 /
-    3,429; 512^2 1,145 / 1,311 / 1,446 / 1,352; 1024^2 384 / 419 / 421 / 407.  Default 3 on a GPU
-    (``STV_IMAGES_PER_GPU``), 1 on the CPU; the results do not depend on it (every kernel of a step is deterministic and an image shares nothing with its neighbours)."""
+    3,429; 512^2 1,145 / 1,311 / 1,446 / 1,352; 1024^2 384 / 419 / 421 / 407.  The results do not depend on it (every
+    kernel of a step is deterministic and an image shares nothing with its neighbours), but device memory does - every
+    image in flight holds its activations and its 2 x 100 L-BFGS history vectors - so it is OPT-IN: the library default
+    is 1; ask for more through the argument or ``STV_IMAGES_PER_GPU``."""
     if requested is None:
-        requested = int(os.environ.get("STV_IMAGES_PER_GPU", "3" if torch.cuda.is_available() else "1"))
+        requested = int(os.environ.get("STV_IMAGES_PER_GPU", "1"))
     return max(1, min(int(requested), n_local))
 
 
@@ -115,7 +117,7 @@ def run_sharded(items: list, fn, *, backend: str | None = None, concurrent: int 
     if k <= 1:
         local = [(i, fn(i, items[i])) for i in mine]
     else:
-        from concurrent.futures import ThreadPoolExecutor  # noqa: PLC0415
+        from concurrent.futures import FIRST_EXCEPTION, ThreadPoolExecutor, wait  # noqa: PLC0415
         dev = torch.cuda.current_device() if torch.cuda.is_available() else None
 
         def worker(i: int):
@@ -123,5 +125,12 @@ def run_sharded(items: list, fn, *, backend: str | None = None, concurrent: int 
                 torch.cuda.set_device(dev)          # the current device is per thread
             return i, fn(i, items[i])
         with ThreadPoolExecutor(max_workers=k, thread_name_prefix="stv-image") as pool:
-            local = list(pool.map(worker, mine))
+            futures = [pool.submit(worker, i) for i in mine]
+            done, pending = wait(futures, return_when=FIRST_EXCEPTION)
+            failed = next((f for f in done if f.exception() is not None), None)
+            if failed is not None:                  # the first failure ends the batch: nothing queued behind it starts
+                for f in pending:
+                    f.cancel()
+                raise failed.exception()
+            local = [f.result() for f in futures]
     return gather_results(local, len(items))

@@ -76,7 +76,7 @@ def stylized_image_path_from_paths(output_dir: Path, content_path: Path, style_p
 
 
 def save_outputs(input_img: torch.Tensor, loss_metrics: LossHistory, output_dir: Path, elapsed: float,
-                 opts: SaveOptions) -> None:
+                 opts: SaveOptions, *, plot_name: str = "loss_plot.png") -> None:
     """Write the final PNG (and the loss plot when matplotlib is present and plotting is on)."""
     try:
         if not output_dir.exists():
@@ -104,7 +104,7 @@ def save_outputs(input_img: torch.Tensor, loss_metrics: LossHistory, output_dir:
             ax.set_ylabel("Loss")
             ax.set_yscale("log")
             ax.legend()
-            fig.savefig(output_dir / "loss_plot.png")
+            fig.savefig(output_dir / plot_name)
             plt.close(fig)
         except ImportError:
             logger.warning("matplotlib not found: skipping loss plot.")

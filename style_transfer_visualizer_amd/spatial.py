@@ -444,7 +444,7 @@ class HaloShard:
             err: Exception | None = None
             try:
                 self._capture_closure()
-            except (RuntimeError, torch.AcceleratorError) as exc:   # a runtime that cannot capture this stream work
+            except RuntimeError as exc:   # a runtime that cannot capture this stream work (torch.AcceleratorError is one)
                 err = exc
             ok = torch.tensor([0.0 if err is not None else 1.0], device=self.x_core.device)
             if self.world > 1:                               # every rank replays, or none does

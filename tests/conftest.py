@@ -80,9 +80,37 @@ class GoldenCase:
     def images(self):
         from style_transfer_visualizer_amd import synthetic
         m = self.meta
+        if m.get("png_inputs"):
+            # what the image loader returns for the 8-bit PNG of the synthetic image (oracle/make_golden.py::png_roundtrip;
+            # reference image_io.py:72-84): uint8 quantisation, /255, Normalize
+            out = []
+            for seed, hw in ((0, m["hw_content"]), (1, m["hw_style"])):
+                t = synthetic.synthetic_image(seed, *hw, normalize=False)[0].mul(255).byte().to(torch.float32).div(255)
+                if m["normalize"]:
+                    mean = torch.tensor([0.485, 0.456, 0.406], dtype=torch.float32).view(3, 1, 1)
+                    std = torch.tensor([0.229, 0.224, 0.225], dtype=torch.float32).view(3, 1, 1)
+                    t = (t - mean) / std
+                out.append(t.unsqueeze(0))
+            return out[0], out[1]
         content = synthetic.synthetic_image(0, *m["hw_content"], normalize=m["normalize"])
         style = synthetic.synthetic_image(1, *m["hw_style"], normalize=m["normalize"])
         return content, style
+
+    def start_image(self) -> torch.Tensor:
+        """x0 of the run (the large fixtures do not store a start image that IS the content image)."""
+        if "x0" in self.arrays:
+            return self.tensor("x0")
+        assert bool(self.arrays["x0_is_content"])
+        return self.images()[0].clone()
+
+    def step_tolerances(self) -> tuple[np.ndarray, np.ndarray]:
+        """Large fixtures: per-step tolerance of the image (relative to its max) and of the three losses
+        (relative): north_star's 1e-4 OUTRIGHT wherever the reference's own trajectory reproduces to a quarter of
+        that under 2-ulp gradient noise (measured per step by oracle/make_golden.py::trajectory_spread), otherwise
+        4x the measured spread."""
+        xs = np.asarray(self.arrays["x_steps_sensitivity"], dtype=np.float64)
+        ls = np.asarray(self.arrays["loss_sensitivity"], dtype=np.float64)
+        return np.maximum(1e-4, 4.0 * xs), np.maximum(1e-4, 4.0 * ls)
 
     def pixel_tolerance(self) -> float:
         """Per-pixel tolerance for x_final, relative to max|x_final|.
@@ -102,6 +130,9 @@ GOLDEN_CASES = [
     "mini_white_adam", "mini_clamp_lbfgs", "mini_clamp_adam", "tiny_taps_lbfgs", "vgg19_white_lbfgs",
     "vgg19_random_adam", "vgg19_content_lbfgs",
 ]
+
+# the two LARGE reference runs (configs[0] literally; 12 full-width L-BFGS steps at 128^2): images stored subsampled
+LARGE_CASES = ["cfg0_256_content_lbfgs50", "vgg19_128_random_lbfgs12"]
 
 
 @pytest.fixture(params=GOLDEN_CASES)

@@ -389,6 +389,38 @@ def test_conv_igemm_every_tile_config(dtype, cfg, case, monkeypatch):
     assert_close(ops.from_nhwc(out), ref2, dtype, 9 * cin, f"cfg {cfg} mask+accum {case}")
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(128, 512, 21, 70, None), (256, 512, 16, 64, 3), (64, 256, 40, 33, 5), (512, 512, 8, 8, 11), (128, 384, 12, 40, 1)])
+def test_conv_xshare_changes_nothing(dtype, case, monkeypatch):
+    """STV_CONV_XSHARE = 2 / 4 deals the channel blocks of a spatial tile to 2 / 4 XCDs (ConvArgs::xshare; the block
+    decode of conv_igemm_kernel.h): another workgroup -> output-block mapping, the same per-block arithmetic - results
+    bit-identical to the default mapping, also where the block count is not divisible by the request (384 / 128 = 3
+    blocks: falls back to 1) and with a second pass (mask + accumulate) on top."""
+    cin, cout, H, W, cfg = case
+    if cfg is not None:
+        monkeypatch.setenv("STV_CONV_CFG", str(cfg))
+    x = ops.to_nhwc(rnd((1, cin, H, W), 141), dtype).to(DEV)
+    w = rnd((cout, cin, 3, 3), 142, -1, 1) * (2.0 / (9 * cin)) ** 0.5
+    wp = ops.block_weights(ops.pack_weights_fwd(w).to(dtype).to(DEV))
+    b = rnd((cout,), 143, -0.2, 0.2).to(DEV)
+    z = ops.to_nhwc(rnd((1, cout, H, W), 144), dtype).to(DEV)
+    prev = ops.to_nhwc(rnd((1, cout, H, W), 145), dtype).to(DEV)
+
+    def both():
+        y = ops.conv_igemm(x, wp, b, flags=ops.RELU_IN | ops.RELU_OUT).clone()
+        out = prev.clone()
+        ops.conv_igemm(x, wp, None, ref=z, out=out, flags=ops.MASK | ops.ACCUM)
+        return y, out
+    monkeypatch.setenv("STV_CONV_XSHARE", "1")
+    base = both()
+    ref = F.relu(F.conv2d(F.relu(ops.from_nhwc(x).cpu()), q(w, dtype), b.cpu(), padding=1))
+    assert_close(ops.from_nhwc(base[0]), ref, dtype, 9 * cin, f"xshare 1 {case}")
+    for g in (2, 4):
+        monkeypatch.setenv("STV_CONV_XSHARE", str(g))
+        got = both()
+        assert torch.equal(got[0], base[0]) and torch.equal(got[1], base[1]), f"xshare {g} {case}"
+
+
 @pytest.mark.parametrize("hint_bytes", [1, 100, 4096, 1 << 20, 5 << 20])
 def test_next_weights_hint_changes_nothing_but_timing(hint_bytes):
     """stv_conv_next_weights: the launch that follows touches one 128-byte line per lane of the hinted range - fewer

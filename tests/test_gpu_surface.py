@@ -310,12 +310,19 @@ def test_style_transfer_batch_runs_independent_pairs(tmp_path, monkeypatch):
     # several images of a rank in flight at once (each on its own host thread and stream; the default is 3): the same
     # images, bit for bit - the seeded start image is drawn under a lock, and nothing else is shared
     from style_transfer_visualizer_amd import parallel
-    assert parallel.images_in_flight(5) == 3 and parallel.images_in_flight(1) == 1 and parallel.images_in_flight(5, 2) == 2
+    assert parallel.images_in_flight(5) == 1 and parallel.images_in_flight(1) == 1 and parallel.images_in_flight(5, 2) == 2   # opt-in
     three = pairs + pairs[:1]
     for k in (2, 3):
         cfg.output.output = str(tmp_path / f"out{k}")
+        cfg.output.log_loss = str(tmp_path / f"out{k}" / "loss.csv")
         par = stv_main.style_transfer_batch(three, cfg, images_per_gpu=k)
         assert len(par) == 3 and all(torch.equal(a, b) for a, b in zip((out[0], out[1], out[0]), par, strict=True)), f"{k} images in flight"
+        # no two pairs write one file: the pair that occurs twice has its index in its PNG name, every pair its own CSV
+        names = sorted(p.name for p in (tmp_path / f"out{k}").iterdir() if p.suffix in (".png", ".csv") and not p.name.startswith("loss_plot"))
+        assert names == ["loss_000.csv", "loss_001.csv", "loss_002.csv", "stylized_c0_x_s_000.png", "stylized_c0_x_s_002.png",
+                         "stylized_c1_x_s.png"], names
+        assert (tmp_path / f"out{k}" / "loss_000.csv").read_text() == (tmp_path / f"out{k}" / "loss_002.csv").read_text()
+    cfg.output.log_loss = None
 
 
 # ------------------------------------------------------------------- a2/a5 replaced content targets

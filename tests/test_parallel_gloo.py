@@ -4,6 +4,7 @@ from __future__ import annotations
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -88,4 +89,24 @@ def test_several_items_in_flight_keep_their_order(monkeypatch):
     monkeypatch.setenv("STV_IMAGES_PER_GPU", "3")
     assert parallel.images_in_flight(10) == 3
     monkeypatch.delenv("STV_IMAGES_PER_GPU")
-    assert parallel.images_in_flight(10) == (3 if torch.cuda.is_available() else 1)
+    assert parallel.images_in_flight(10) == 1                 # opt-in: the library default is one image at a time
+
+
+def test_first_failure_cancels_what_has_not_started():
+    """Several items in flight: the first exception ends the batch - items still queued behind it never start, and the
+    caller sees that exception (not a later one, and not after every other item ran to completion)."""
+    import threading
+    import time
+    started, lock = [], threading.Lock()
+
+    def fn(i, item):
+        with lock:
+            started.append(i)
+        if i == 0:
+            time.sleep(0.05)
+            raise RuntimeError("item 0 failed")
+        time.sleep(0.3)
+        return torch.tensor([float(item)])
+    with pytest.raises(RuntimeError, match="item 0 failed"):
+        parallel.run_sharded(list(range(8)), fn, concurrent=2)
+    assert len(started) < 8, started

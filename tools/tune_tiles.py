@@ -53,8 +53,15 @@ for key, cnt in sorted(votes.items()):
     cfg = analytic if analytic in best else min(best)
     entries.append(dict(H=H, W=W, cin=cin, cout=cout, taps=taps, elem_bytes=eb, cfg=cfg, analytic=analytic,
                         votes={str(c): v for c, v in sorted(cnt.items())}))
-doc = {"tool": "tools/tune_tiles.py", "rounds": args.rounds, "device": torch.cuda.get_device_name(0),
-       "arch": str(torch.cuda.get_device_properties(0).gcnArchName).split(":")[0],
+_props = torch.cuda.get_device_properties(0)
+# torch reports the generic marketing string ("AMD Radeon Graphics") on the MI355X boxes of this pool: record what does
+# identify the device and the box - arch with its feature string, CU count, memory, UUID, host name
+doc = {"tool": "tools/tune_tiles.py", "rounds": args.rounds,
+       "device": f"MI355X ({torch.cuda.get_device_name(0)}; {_props.gcnArchName}, {_props.multi_processor_count} CUs, "
+                 f"{_props.total_memory / 2**30:.0f} GiB)",
+       "box": {"host": __import__("socket").gethostname(), "uuid": str(getattr(_props, "uuid", "")),
+               "rocm": str(torch.version.hip)},
+       "arch": str(_props.gcnArchName).split(":")[0],
        "date": datetime.date.today().isoformat(), "entries": entries}
 with open(args.out, "w") as fh:
     json.dump(doc, fh, indent=1)
