@@ -127,6 +127,15 @@ int stv_conv_tune(int H, int W, int cin, int cout, int taps, int dtype, void* st
 int stv_conv_tune_export(int* out7, int max_entries);
 int stv_conv_tune_import(const int* in7, int n_entries);
 
+/* Scratch for convolutions that split K across workgroups (small-grid 3x3 bf16 layers: two workgroups share an
+ * output tile, each walks half of K, the later one adds the other's fp32 partial sums - a + b in fp32, the same
+ * whichever came first - and runs the epilogue).  Caller-owned device memory of at least
+ * stv_conv_workspace_bytes() bytes, ZEROED once by the caller (the kernels leave it zeroed); applies to the conv
+ * launches this host thread makes until it is changed; NULL / 0 clears it (then no launch splits K).  One
+ * workspace must not serve two launches that run at the same time.  No reference counterpart: an execution
+ * detail under F.conv2d (core_model.py:316). */
+void stv_conv_workspace(void* ws, size_t bytes);
+size_t stv_conv_workspace_bytes(void);
 /* Hint for the NEXT stv_conv_igemm* launch issued from this thread: `bytes` of weights that the conv launched AFTER
  * it will read.  That next launch touches them (one 128-byte line per lane, between its main loop and its epilogue) so
  * they are on chip when their own launch starts.  One shot: the launch that follows on this thread consumes the hint

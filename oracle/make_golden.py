@@ -119,15 +119,22 @@ def per_step_sensitivity(weights, cfg, content, style, x0, *, style_layers, cont
     return out
 
 
+SPREAD_EPS = (3e-7, 3e-6, 3e-5, 3e-4)
+
+
 def trajectory_spread(weights, cfg, content, style, x0, *, style_layers, content_layers, style_w,
-                      content_w, steps, optimizer, adam_lr, eps=3e-7):
-    """The two measures above plus the spread of the LOGGED LOSSES, from one set of seven oracle runs (the large
-    fixtures: a run is minutes).  Returns (x_final sensitivity, per-step image sensitivity [steps], per-step
-    relative loss spread [steps, 3] in the order style / content / total)."""
+                      content_w, steps, optimizer, adam_lr, eps_levels=SPREAD_EPS):
+    """The two measures above plus the spread of the LOGGED LOSSES, per perturbation level (the large fixtures: a run is
+    seconds to minutes).  The gradient of every step is multiplied by (1 + eps*N(0,1)) - once per step as a whole, once per
+    element, three seeds each - for eps = 3e-7 (two fp32 ulps: another summation order of the SAME kernels), 3e-6 and 3e-5
+    (what a different but equally valid fp32 evaluation of a 9*Cin-term convolution sum, or of a Gram sum over 1e5 pixels,
+    differs by) and 3e-4 (the rms size of what a handful of ReLU / max-pool near-ties decided the other way do to the
+    gradient of a 256x256 image).  Returns (x sensitivity [E, steps], relative loss spread [E, steps, 3] in the order style / content /
+    total): a test picks the level at which ITS gradient measurably differs from the reference's at step 1."""
     model = ocm.OracleModel(ocm.vgg_program(weights, cfg), style_layers, content_layers)
     model.set_targets(style, content)
 
-    def run(seed, elementwise=False):
+    def run(seed, eps, elementwise=False):
         gen = torch.Generator().manual_seed(seed)
 
         def lg(x):
@@ -141,20 +148,21 @@ def trajectory_spread(weights, cfg, content, style, x0, *, style_layers, content
                                  keep_steps=True)
         h = res["history"]
         return res["x_steps"], np.stack([np.asarray(h["style"]), np.asarray(h["content"]), np.asarray(h["total"])], axis=1)
-    base_x, base_l = run(0)
-    x_sens, l_sens = np.zeros(steps), np.zeros((steps, 3))
-    for s in (1, 2, 3):
-        for ew in (False, True):
-            xs, ls = run(s, ew)
-            for k, (a, b) in enumerate(zip(xs, base_x, strict=True)):
-                scale = float(b.abs().max())
-                dev = float((a - b).abs().max()) / scale if np.isfinite(scale) and scale > 0 else float("nan")
-                x_sens[k] = max(x_sens[k], dev) if np.isfinite(dev) else float("nan")
-            with np.errstate(divide="ignore", invalid="ignore"):
-                rel = np.abs(ls - base_l) / np.abs(base_l)
-            rel[~np.isfinite(rel)] = 0.0          # a loss that is exactly zero in both runs (content start, step 1)
-            l_sens = np.maximum(l_sens, rel)
-    return float(x_sens[-1]), x_sens, l_sens
+    base_x, base_l = run(0, 0.0)
+    x_sens, l_sens = np.zeros((len(eps_levels), steps)), np.zeros((len(eps_levels), steps, 3))
+    for e_i, eps in enumerate(eps_levels):
+        for s in (1, 2, 3):
+            for ew in (False, True):
+                xs, ls = run(s, eps, ew)
+                for k, (a, b) in enumerate(zip(xs, base_x, strict=True)):
+                    scale = float(b.abs().max())
+                    dev = float((a - b).abs().max()) / scale if np.isfinite(scale) and scale > 0 else float("nan")
+                    x_sens[e_i, k] = max(x_sens[e_i, k], dev) if np.isfinite(dev) else float("nan")
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    rel = np.abs(ls - base_l) / np.abs(base_l)
+                rel[~np.isfinite(rel)] = 0.0          # a loss that is exactly zero in both runs (content start, step 1)
+                l_sens[e_i] = np.maximum(l_sens[e_i], rel)
+    return x_sens, l_sens
 
 
 def png_roundtrip(seed, h, w, *, normalize):
@@ -173,7 +181,7 @@ def png_roundtrip(seed, h, w, *, normalize):
 def run_case(ref, name, *, cfg, cfg_name, wseed, hw_content, hw_style, style_layers,
              content_layers, init_method, steps, optimizer, style_w=1e5, content_w=1.0,
              gain_first=1.0, bias_scale=0.0, normalize=True, adam_lr=1e-3,
-             subsample_targets=False, store_steps=False, png_inputs=False, compact=0, log_every=2):
+             subsample_targets=False, store_steps=False, png_inputs=False, compact=0, log_every=2, full_steps=()):
     ref_core, ref_opt, ref_config, _ = ref
     weights = _weights(cfg, wseed, gain_first, bias_scale)
     ref_core.initialize_vgg = lambda: ref_harness.build_sequential(weights, cfg)
@@ -212,6 +220,7 @@ def run_case(ref, name, *, cfg, cfg_name, wseed, hw_content, hw_style, style_lay
     logged = []
     x_steps = []
     states = []
+    full = {}              # k -> (image after step k, the gradient step k + 1 evaluated there)
 
     def on_end(metrics):
         if metrics.step == 1:
@@ -219,6 +228,10 @@ def run_case(ref, name, *, cfg, cfg_name, wseed, hw_content, hw_style, style_lay
         logged.append((metrics.step, metrics.has_values))
         if store_steps:
             x_steps.append(input_img.detach().clone().numpy())
+        if metrics.step in full_steps:
+            full[metrics.step] = [input_img.detach().clone().numpy(), None]
+        if metrics.step - 1 in full:                       # this step's closure evaluated the image stored above
+            full[metrics.step - 1][1] = input_img.grad.detach().clone().numpy()
         if compact and optimizer == "lbfgs":          # torch.optim.LBFGS keeps its state under its first parameter
             st = opt.state[opt._params[0]]
             states.append((int(st.get("n_iter", 0)), len(st.get("old_dirs") or [])))
@@ -252,11 +265,21 @@ def run_case(ref, name, *, cfg, cfg_name, wseed, hw_content, hw_style, style_lay
     if compact:
         # the large fixtures: images subsampled (every `compact`-th row and column) + float64 checksums of the whole
         k = compact
-        sens, x_sens, l_sens = trajectory_spread(weights, cfg, content, style, x0, **spread_kw)
+        x_sens, l_sens = trajectory_spread(weights, cfg, content, style, x0, **spread_kw)
+        sens = float(x_sens[0, -1])
         xf, g1 = out_img.detach().numpy(), grads["g1"].numpy()
+        for k_full, (img, grad) in sorted(full.items()):
+            # a FULL image of the reference's trajectory + what the reference computed there (the loss triple is
+            # total_loss[k_full] etc. - step k_full + 1 evaluates the image after step k_full): the chaos-free rows
+            arrays[f"x_after_step_{k_full}"] = img
+            assert grad is not None, "full_steps must leave a following step to evaluate the image"
+            arrays[f"grad_at_step_{k_full + 1}_sub"] = grad[..., ::k, ::k].copy()
+            arrays[f"grad_at_step_{k_full + 1}_absmax"] = np.asarray(np.abs(grad).max())
         arrays.update({
             "x_final_sensitivity": np.asarray(sens, dtype=np.float64),
+            "sens_eps": np.asarray(SPREAD_EPS, dtype=np.float64),
             "x_steps_sensitivity": x_sens, "loss_sensitivity": l_sens,
+            "grad_step1_rms_sub": np.asarray(float(np.sqrt(np.mean(np.square(g1[..., ::k, ::k].astype(np.float64)))))),
             "x_final_sub": xf[..., ::k, ::k].copy(), "x_final_sum": np.asarray(xf.astype(np.float64).sum()),
             "x_final_abs_sum": np.asarray(np.abs(xf.astype(np.float64)).sum()), "x_final_absmax": np.asarray(np.abs(xf).max()),
             "grad_step1_sub": g1[..., ::k, ::k].copy(), "grad_step1_abs_sum": np.asarray(np.abs(g1.astype(np.float64)).sum()),
@@ -304,6 +327,7 @@ def run_case(ref, name, *, cfg, cfg_name, wseed, hw_content, hw_style, style_lay
         init_method=init_method, steps=steps, optimizer=optimizer, style_w=style_w,
         content_w=content_w, gain_first=gain_first, bias_scale=bias_scale,
         normalize=normalize, adam_lr=adam_lr, png_inputs=png_inputs, compact=compact, log_every=log_every,
+        full_steps=list(full_steps),
         block_count=len(model.vgg_blocks), style_ids=list(model.style_ids),
         content_ids=list(model.content_ids),
         torch_version=torch.__version__,
@@ -395,11 +419,11 @@ def main(argv=None):
     # synthetic images (what the config tests feed ``cli.main``).
     case("cfg0_256_content_lbfgs50", cfg=synthetic.VGG19_CFG, cfg_name="vgg19", wseed=0, hw_content=(256, 256),
          hw_style=(256, 256), style_layers=S, content_layers=C, init_method="content", steps=50, optimizer="lbfgs",
-         subsample_targets=True, png_inputs=True, compact=4, log_every=10)
+         subsample_targets=True, png_inputs=True, compact=4, log_every=10, full_steps=(49,))
     # full width, the reference's default start (random), 12 L-BFGS steps at 128x128: the image after every step
     case("vgg19_128_random_lbfgs12", cfg=synthetic.VGG19_CFG, cfg_name="vgg19", wseed=0, hw_content=(128, 128),
          hw_style=(128, 160), style_layers=S, content_layers=C, init_method="random", steps=12, optimizer="lbfgs",
-         subsample_targets=True, store_steps=True, compact=2)
+         subsample_targets=True, store_steps=True, compact=2, full_steps=(5, 11))
 
 
 if __name__ == "__main__":

@@ -74,6 +74,8 @@ SIGNATURES = {
     "stv_conv_tune_export": (c_int, [ctypes.POINTER(c_int), c_int]),
     "stv_conv_tune_import": (c_int, [ctypes.POINTER(c_int), c_int]),
     "stv_conv_next_weights": (None, [c_void_p, c_size_t]),
+    "stv_conv_workspace": (None, [c_void_p, c_size_t]),
+    "stv_conv_workspace_bytes": (c_size_t, []),
     "stv_conv_num_configs": (c_int, []),
     "stv_conv_uses_ws": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "stv_conv_config": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),

@@ -29,7 +29,14 @@ struct ConvArgs {
   // tile on the tile's XCD (each L2 fetches ALL weights, the input once), g = the channel blocks dealt to g XCDs
   // (each L2 fetches 1/g of the weights, the input g times)
   int xshare = 1;
+  // K split ACROSS workgroups (conv_igemm_kernel.h, "XK"): 2 = two workgroups share an output tile, each walks half of
+  // K; the one that finishes second adds the other's fp32 partial sums (exchanged through xk_ws) and runs the epilogue.
+  // For layers whose grid cannot give every CU a workgroup on a large tile (the 64 x 64-pixel 512-channel layers of a
+  // 512 x 512 image).  xk_ws: caller-owned scratch (stv_conv_workspace), zeroed once; the kernel leaves it zeroed.
+  int xk = 1;
+  void* xk_ws = nullptr;
 };
+constexpr int kXkSlabOffset = 65536;       // bytes: [ticket, flag] pairs of up to 8,192 output tiles, then the fp32 slabs
 
 // conv_ws.hip: weight-stationary persistent kernel for 3x3, Cin = 64, bf16 (the short-K layers).
 // stv_conv_ws_supported() says whether a launch with these arguments can take it.

@@ -56,6 +56,9 @@ __device__ unsigned long long g_stv_stamps[8 * 16384];
 
 thread_local const void* g_stv_next_w = nullptr;
 thread_local uint32_t g_stv_next_w_bytes = 0;
+// Scratch for the K split across workgroups (stv_conv_workspace): the caller's buffer, for the launches of this thread
+thread_local void* g_stv_conv_ws = nullptr;
+thread_local size_t g_stv_conv_ws_bytes = 0;
 
 namespace {
 
@@ -206,6 +209,34 @@ int launch_mfma(const ConvArgs& a, int cfg, hipStream_t st) {
   }
 }
 
+// K split across workgroups (ConvArgs::xk): a 3x3 bf16 layer whose output is so small that the 8 x 32-pixel x
+// 64-channel tile leaves at least half of the CUs without a workgroup (the 64 x 64-pixel layers of a 512 x 512 image: 128
+// tiles), on a K deep enough to halve (Cin >= 256) - every CU then works on one K half of such a tile instead of two
+// CUs' worth of workgroups sharing a CU on tiles half the size (0.20 against 0.35 LDS-DMA pieces per MFMA).
+// STV_CONV_XK: 0 never, 1 where the rule above holds and the caller provided scratch (stv_conv_workspace); default from
+// the measurement recorded in DESIGN.md.
+#ifndef STV_CONV_XK_DEFAULT
+#define STV_CONV_XK_DEFAULT 0
+#endif
+template <typename T, int TAPS>
+bool xk_wanted(const ConvArgs& a) {
+  if (sizeof(T) != 2 || TAPS != 9) return false;
+  const char* knob = getenv("STV_CONV_XK");
+  if ((knob ? atoi(knob) : STV_CONV_XK_DEFAULT) == 0 || getenv("STV_CONV_CFG") != nullptr) return false;
+  if (a.cin < 256 || a.cout % 64 != 0 || g_stv_conv_ws == nullptr) return false;
+  const long blocks = (long)ceil_div(a.W, 32) * ceil_div(a.H, 8) * (a.cout / 64);
+  const long padded = (blocks + 7) / 8 * 8;
+  if (2 * padded > 256 || blocks < 96) return false;                    // every K half on a CU of its own, most CUs busy
+  return (size_t)kXkSlabOffset + (size_t)blocks * (8 * 32 * 64 * 4) <= g_stv_conv_ws_bytes && blocks * 8 <= kXkSlabOffset;
+}
+template <typename T, int TAPS>
+int launch_xk(const ConvArgs& a, hipStream_t st) {
+  ConvArgs b = a;
+  b.xk = 2;
+  b.xk_ws = g_stv_conv_ws;
+  return launch_cfg<Cfg<T, 8, 64, 4, 2, TAPS>>(b, st);
+}
+
 template <typename T, int TAPS>
 int launch_typed(const ConvArgs& a, hipStream_t st) {
   // short-K layers (Cin = 64, bf16): weight-stationary persistent kernel (conv_ws.hip)
@@ -214,6 +245,7 @@ int launch_typed(const ConvArgs& a, hipStream_t st) {
     g_stv_next_w_bytes = 0;
     return stv_conv_ws_launch(a, st);
   }
+  if (xk_wanted<T, TAPS>(a)) return launch_xk<T, TAPS>(a, st);
   int cfg = choose_cfg(a.H, a.W, a.cin, a.cout, (int)sizeof(T), TAPS);
   if ((cfg == 7 || cfg == 8 || cfg == 11 || cfg == 12 || cfg == 16 || cfg == 17) && a.pool != nullptr) cfg = 4;      // one row per wave: no pooling window
   if (cfg < 0) {
@@ -462,6 +494,15 @@ extern "C" int stv_conv_igemm_pool(const void* x, const void* w, const float* bi
 
 extern "C" int stv_conv_num_configs(void) { return kNumCfg; }
 
+extern "C" void stv_conv_workspace(void* ws, size_t bytes) {
+  g_stv_conv_ws = (ws != nullptr && bytes > (size_t)kXkSlabOffset) ? ws : nullptr;
+  g_stv_conv_ws_bytes = g_stv_conv_ws ? bytes : 0;
+}
+
+extern "C" size_t stv_conv_workspace_bytes(void) {
+  return (size_t)kXkSlabOffset + (size_t)128 * (8 * 32 * 64 * 4);       // the largest launch that splits K: 128 tiles of 8 x 32 x 64
+}
+
 extern "C" void stv_conv_next_weights(const void* w, size_t bytes) {
   g_stv_next_w = (bytes > 0 && bytes < ((size_t)1 << 31)) ? w : nullptr;
   g_stv_next_w_bytes = g_stv_next_w ? (uint32_t)bytes : 0;
@@ -479,6 +520,7 @@ extern "C" int stv_conv_igemm_route(const void* x, const void* w, const void* po
   a.route_idx = pool_idx;
   a.route_out = y_full;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (xk_wanted<bf16_t, 9>(a)) return launch_xk<bf16_t, 9>(a, st);
   int cfg = choose_cfg(H, W, cin, cout, 2, kRouteTaps);
   return launch_mfma<bf16_t, 9>(a, cfg, st);                                   // always the general kernel
 }

@@ -140,6 +140,7 @@ struct Phase {
   int cin;
   bool w_blocked;
   uint32_t relu_floor;
+  int k_first, k_count;      // the K-stages this workgroup walks (all of them unless K is split across workgroups)
 };
 struct Geom {
   int H, W, cout, x0, y0, n0;
@@ -194,14 +195,15 @@ __device__ __forceinline__ void conv_mainloop(const Phase<typename C::Elem>& ph,
   }
   // group g walks the K-stages g, g + KS, ...: `l` counts its own stages (every group runs the
   // same number of rounds so that the workgroup barriers match; a round past the end stages zeros)
-  const int nrounds = (nchunks + C::KS - 1) / C::KS;
+  const int nrounds = (ph.k_count + C::KS - 1) / C::KS;
   char* const ring = smem + grp * (C::NBUF * C::STAGE_BYTES);
   // issue piece j of this wave's share of round l into ring buffer `buf`
   auto dma = [&](int j, int l, char* buf) {
     const int g = piece_id(j);
-    const int stage = l * C::KS + grp;
+    const int own = l * C::KS + grp;               // index among this workgroup's stages
+    const int stage = ph.k_first + own;
     const bool in = g < C::IN_PIECES;
-    const bool live = g < C::PIECES && stage < nchunks && !(STV_DIAG & 1);
+    const bool live = g < C::PIECES && own < ph.k_count && !(STV_DIAG & 1);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<T*>(in ? ph.x : ph.w), 0, live ? (in ? x_bytes : w_bytes) : 0, 0x00020000);
     char* dst = buf + (g < C::PIECES ? g * 1024 : C::SPARE_OFF);
@@ -567,9 +569,19 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
   // (with a plain 2-D grid every channel block streamed the whole input from HBM again).
   const int ntiles = tiles_x * ((a.H + C::TH - 1) / C::TH);
   const int ny = (a.cout + C::BN - 1) / C::BN;
+  // K split across workgroups (ConvArgs::xk): blocks b and b + 8 - same XCD, dispatched back to back - are the two K
+  // halves of one output tile; the grid is padded to whole groups of eight tiles
+  int blk = (int)blockIdx.x, kh = 0;
+  constexpr bool kXkTile = C::KS == 1 && !C::M16 && sizeof(T) == 2;
+  const bool xk = kXkTile && a.xk == 2;
+  if (xk) {
+    kh = (blk >> 3) & 1;
+    blk = ((blk >> 4) << 3) | (blk & 7);
+    if (blk >= ntiles * ny) return;                  // (padding blocks: before any barrier)
+  }
   int tile, yb;
   {
-    const int round = 8 * ny, b = (int)blockIdx.x;
+    const int round = 8 * ny, b = blk;
     const int grp8 = b / round, within = b - grp8 * round;
     const int left = ntiles - grp8 * 8;                    // tiles in this group of (up to) eight
     const int span = left < 8 ? left : 8;
@@ -629,7 +641,8 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
 
   constexpr uint32_t kOob = 0x80000000u;   // >= num_records for every tensor this kernel accepts
   const Geom geom{a.H, a.W, a.cout, x0, y0, n0, lane, wave, grp, wm, wn, r, h};
-  const Phase<T> ph1{xin, wgt, a.cin, w_blocked, relu_floor};
+  const int khalf = (nchunks + 1) >> 1;
+  const Phase<T> ph1{xin, wgt, a.cin, w_blocked, relu_floor, (xk && kh) ? khalf : 0, xk ? (kh ? nchunks - khalf : khalf) : nchunks};
   if constexpr (C::M16) {
     f32x4 a16[C::MT][2][C::NT][2];
 #pragma unroll
@@ -684,8 +697,9 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
       }
       using C1 = Cfg<T, C::TH, C::BN, C::WM, C::WN, 1, C::KS, C::NBUF, C::M16>;
       static_assert(C1::RING_BYTES <= C::LDS_BYTES, "the 1x1 pass reuses the 3x3 ring");
+      const int nch2 = a.cin2 / C::CK, kh2 = (nch2 + 1) >> 1;       // (the 1x1 term's K is split like the first term's)
       const Phase<T> ph2{static_cast<const T*>(a.x2), static_cast<const T*>(a.w2), a.cin2, false,
-                         sizeof(T) == 2 ? 0x80008000u : 0x80000000u};
+                         sizeof(T) == 2 ? 0x80008000u : 0x80000000u, (xk && kh) ? kh2 : 0, xk ? (kh ? nch2 - kh2 : kh2) : nch2};
       if constexpr (C::M16) {            // the 1x1 product in blocks of its own, then added in the epilogue's layout
         f32x4 b16[C::MT][2][C::NT][2];
 #pragma unroll
@@ -700,6 +714,60 @@ __global__ __launch_bounds__(C::THREADS) void conv_igemm_kernel(ConvArgs a) {
         acc16_to_acc32<C>(b16, acc, true);
       } else {
         conv_mainloop<C1, false>(ph2, geom, smem, acc);
+      }
+    }
+  }
+
+  // ---- K split across workgroups: the two halves meet here, on raw sums (mask and 1x1 term above are linear in them) ----
+  // The workgroup that finishes FIRST (ticket 0) leaves its accumulators in the tile's slab - lane-linear, device-scope
+  // write-through stores - raises the tile's flag and exits; the second waits for the flag, adds the slab to its own
+  // sums and runs the epilogue.  a + b == b + a in fp32, so the result does not depend on who came first; both words
+  // are zero again when the kernel ends.  The spin is bounded (the first workgroup holds ticket 0 only once it is past
+  // its main loop: it is resident and a few hundred nanoseconds from raising the flag).
+  if constexpr (kXkTile) {
+    if (xk) {
+      __shared__ int s_role;
+      uint32_t* tk = static_cast<uint32_t*>(a.xk_ws) + 2 * blk;
+      float* slab = reinterpret_cast<float*>(static_cast<char*>(a.xk_ws) + kXkSlabOffset) + (size_t)blk * (C::BM * C::BN);
+      const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(slab, 0, C::BM * C::BN * 4, 0x00020000);
+      if (tid == 0) s_role = (int)__hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      const int role = s_role;
+      constexpr int kSc1 = 16;                           // device-scope cache policy (sc1): coherent across the XCDs' L2s
+      if (role == 0) {
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+              const u32x4 v = {__float_as_uint(acc[mt][nt][4 * q4]), __float_as_uint(acc[mt][nt][4 * q4 + 1]),
+                               __float_as_uint(acc[mt][nt][4 * q4 + 2]), __float_as_uint(acc[mt][nt][4 * q4 + 3])};
+              __builtin_amdgcn_raw_buffer_store_b128(v, rs_s, (uint32_t)(((((mt * C::NT + nt) * 4 + q4) * C::THREADS) + tid) * 16), 0, kSc1);
+            }
+        wait_vmcnt<0>();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(tk + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+      }
+      if (tid == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(tk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(2);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_s, (uint32_t)(((((mt * C::NT + nt) * 4 + q4) * C::THREADS) + tid) * 16), 0, kSc1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[mt][nt][4 * q4 + e] += __uint_as_float(v[e]);
+          }
+      if (tid == 0) {                                    // ready for the next launch that uses this workspace
+        __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(tk + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   }
@@ -968,7 +1036,9 @@ int launch_cfg(const ConvArgs& a_in, hipStream_t st) {
                         : reinterpret_cast<const void*>(&conv_igemm_kernel<C, false>);
   if (stv_set_max_lds(fn, C::LDS_BYTES) != STV_OK) return STV_ERR_LAUNCH;
   const int tiles = ceil_div(a.W, C::TW) * ceil_div(a.H, C::TH);
-  dim3 grid(tiles * ceil_div(a.cout, C::BN));      // decoded XCD-aware in the kernel
+  const int blocks = tiles * ceil_div(a.cout, C::BN);
+  if (a.xk == 2 && !(C::KS == 1 && !C::M16 && sizeof(typename C::Elem) == 2 && a.xk_ws != nullptr)) return STV_ERR_ARG;
+  dim3 grid(a.xk == 2 ? 2 * ((blocks + 7) / 8 * 8) : blocks);      // decoded XCD-aware in the kernel
   if (relu) hipLaunchKernelGGL((conv_igemm_kernel<C, true>), grid, dim3(C::THREADS), C::LDS_BYTES, st, a);
   else hipLaunchKernelGGL((conv_igemm_kernel<C, false>), grid, dim3(C::THREADS), C::LDS_BYTES, st, a);
   STV_CHECK_LAUNCH();

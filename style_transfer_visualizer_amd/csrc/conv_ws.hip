@@ -46,6 +46,9 @@
 #ifndef STV_WS_F_AUX
 #define STV_WS_F_AUX 0       // ... of the z-tile DMA (backward form: last use of that map in the step)
 #endif
+#ifndef STV_WS_SWEEP
+#define STV_WS_SWEEP 1       // forward form behind a ReLU: clamp the staged halo tile ONCE in LDS (0: every A fragment after its read)
+#endif
 #ifndef STV_WS128_DEFAULT
 #define STV_WS128_DEFAULT 1  // the 128 -> 128 layer on this kernel unless STV_CONV_WS128=0
 #endif
@@ -78,6 +81,8 @@ template <int CIN> struct WsGeom {
   static constexpr int NCOL = 3 * NSTAGE;                    // tap columns of a tile: (stage, dx)
   static constexpr int NCHUNK = 3 * MT;                      // deferred epilogue chunks: MT row stores + 2 MT pooling half-steps
   static constexpr int SPW = NSTAGE / 4;                     // K-stages each wave fetches per tile
+  static constexpr int NSWEEP = IN_BYTES / 4096;             // 16-byte slots of a halo tile per thread (ReLU sweep): 11 / 10
+  static_assert(IN_BYTES % 4096 == 0 && NSWEEP < NCOL, "ReLU sweep: whole rounds of 256 slots, one per tap column");
   static_assert(NCHUNK <= NCOL, "one epilogue chunk per tap column");
 };
 
@@ -236,6 +241,36 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgrou
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
 
+  // ---- ReLU on the input, once per staged tile (forward form behind a tapped layer: the stored map is pre-ReLU) -----
+  // Per fragment the packed max costs 4 VALU x 3 dx x (MT + 2) rows x NSTAGE stages per wave and tile (288 for Cin = 64:
+  // every staged value is clamped six times over - three tap columns, two channel halves of the workgroup); as a sweep
+  // over the landed tile it is one 16-byte slot per thread and round, NSWEEP rounds: 44 VALU + 22 LDS operations.  The
+  // sweep of tile k + 1 rides under the MFMAs of tile k, one round per tap column (read in one column, clamp + write in
+  // the next), and the barrier at the end of tile k publishes it.  For that the tile has to have LANDED when tile k
+  // starts: the wait at the end of a tile covers everything this wave has in flight (vmcnt 0: the halo tile requested a
+  // whole tile ago, and the previous tile's deferred stores - loads and stores retire out of order with respect to each
+  // other, so a counted wait could not tell them apart).
+  constexpr bool sweep = !DG && RELU_IN && (STV_WS_SWEEP != 0);
+  bf16x8v swv[2];
+  auto sweep_read = [&](char* buf, int c, int set) {
+    swv[set] = *reinterpret_cast<const bf16x8v*>(buf + (c * 256 + tid) * 16);
+  };
+  auto sweep_write = [&](char* buf, int c, int set) {      // (whole-vector packed max, as relu_frag does for a fragment)
+    *reinterpret_cast<bf16x8v*>(buf + (c * 256 + tid) * 16) = relu_frag(swv[set], 0u);
+  };
+  if constexpr (sweep) {                             // the first tile has nobody's MFMAs to hide behind
+    if (t_first < ntiles) {
+#pragma unroll
+      for (int c = 0; c < G::NSWEEP; ++c) {
+        sweep_read(smem, c, c & 1);
+        sweep_write(smem, c, c & 1);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the sweep's LDS writes are done before the others read
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+
   // ---- forward form: the epilogue of tile k runs in the shadow of tile k + 1's MFMAs ------------------
   // One wave per SIMD has no other wave to overlap its epilogue with, but its own MFMAs leave seven of eight
   // issue slots to the vector ALU.  At the end of a tile only the rounding (acc -> packed bf16 words Pp, 64
@@ -356,7 +391,7 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgrou
     // ReLU) clamped one column ahead, in the shadow of the 12 MFMAs in between.
     auto load_col = [&](int col, int set) { load_col_from(cur, col, set); };
     auto relu_col = [&](int set) {
-      if (RELU_IN) {
+      if (RELU_IN && !sweep) {
 #pragma unroll
         for (int j = 0; j < AROWS; ++j) af[set][j] = relu_frag(af[set][j], 0u);
       }
@@ -371,6 +406,11 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgrou
     for (int col = 0; col < NCOL; ++col) {
       const int s = col / 3, dx = col - s * 3;
       if (col + 2 < NCOL) load_col(col + 2, (col + 2) % 3);
+      if constexpr (sweep) {                           // the NEXT tile's buffer (no next tile: a buffer nobody reads again)
+        char* const nxt_buf = smem + ((slot + 1 == NB) ? 0 : slot + 1) * WsLds<CIN, DG>::BUF;
+        if (col < G::NSWEEP) sweep_read(nxt_buf, col, col & 1);
+        if (col >= 1 && col - 1 < G::NSWEEP) sweep_write(nxt_buf, col - 1, (col - 1) & 1);
+      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy)
@@ -433,9 +473,11 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgrou
     // The previous tile's deferred stores count too: they can only make the wait longer, never satisfied
     // early (the threshold is exactly the newest DMA's size).
     const bool more = t + NB * tstride < ntiles && !(diag & 2);
-    if (NB == 3 && t + 2 * tstride < ntiles && !(diag & 2)) wait_vmcnt<kTileOps>();
+    if (!sweep && NB == 3 && t + 2 * tstride < ntiles && !(diag & 2)) wait_vmcnt<kTileOps>();
     else wait_vmcnt<0>();
+    if constexpr (sweep) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the next tile's sweep: its writes were issued columns ago
     __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     if (NB == 2 && more) issue_tile(t + NB * tstride, cur);
 
     if (NB == 3 && more) issue_tile(t + NB * tstride, cur);      // forward form: the stores follow in the next tile's shadow

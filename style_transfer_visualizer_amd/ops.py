@@ -104,6 +104,20 @@ def from_nhwc(x: torch.Tensor) -> torch.Tensor:
 
 # ---- conv ---------------------------------------------------------------------
 
+def conv_workspace_bytes() -> int:
+    return int(_lib.load().stv_conv_workspace_bytes())
+
+
+def set_conv_workspace(ws: torch.Tensor | None) -> None:
+    """Scratch for convolutions that split K across workgroups (``stv_conv_workspace``): a ZEROED uint8 device tensor of
+    ``conv_workspace_bytes()`` bytes the caller keeps alive, for the conv launches of this host thread; ``None`` clears it."""
+    lib = _lib.load()
+    if ws is None:
+        lib.stv_conv_workspace(None, 0)
+    else:
+        lib.stv_conv_workspace(_ptr(ws), ws.numel() * ws.element_size())
+
+
 def conv_first_pack(wf: torch.Tensor) -> torch.Tensor:
     """Kernel-side packing of a frozen first-layer weight [9,Cout,Cin] (fp32), done once (stv_conv_first_pack)."""
     _, cout, cin = wf.shape

@@ -554,19 +554,35 @@ class Program:
         self.op_meta = [(int(o.op), int(o.H), int(o.W), int(o.cin), int(o.cout), int(o.taps), int(o.n))
                         for o in op_list]
         self.op_flags = [int(o.flags) for o in op_list]
+        # scratch of the convolutions that split K across workgroups (stv_conv_workspace, include/stv.h): owned here,
+        # zeroed once, handed to the library around every run of THIS program (its launches are one chain on one stream;
+        # the pointer is baked into the captured graph, which this object outlives)
+        self._conv_ws = None
+        if any(int(o.op) == _lib.OP_CONV and int(o.dtype) == _lib.STV_BF16 and int(o.taps) == 9 for o in op_list) and torch.cuda.is_available():
+            self._conv_ws = torch.zeros(int(lib.stv_conv_workspace_bytes()), dtype=torch.uint8, device=torch.cuda.current_device())
+
+    def _with_workspace(self, call):
+        lib = _lib.load()
+        if self._conv_ws is None:
+            return call()
+        lib.stv_conv_workspace(self._conv_ws.data_ptr(), self._conv_ws.numel())
+        try:
+            return call()
+        finally:
+            lib.stv_conv_workspace(None, 0)
 
     def run(self, use_graph: bool = False) -> None:
         lib = _lib.load()
-        _lib.check(lib.stv_program_run(self._handle, 1 if use_graph else 0,
-                                       torch.cuda.current_stream().cuda_stream), "stv_program_run")
+        self._with_workspace(lambda: _lib.check(lib.stv_program_run(
+            self._handle, 1 if use_graph else 0, torch.cuda.current_stream().cuda_stream), "stv_program_run"))
 
     def profile(self, reps: int = 1) -> list[float]:
         """Per-op device milliseconds (HIP events on the current stream); synchronises.  ``reps`` > 1
         launches every op that many times inside its event pair (timing only: buffers are then garbage)."""
         lib = _lib.load()
         out = (ctypes.c_float * self.n_ops)()
-        _lib.check(lib.stv_program_profile_reps(self._handle, torch.cuda.current_stream().cuda_stream, int(reps), out,
-                                                self.n_ops), "stv_program_profile_reps")
+        self._with_workspace(lambda: _lib.check(lib.stv_program_profile_reps(
+            self._handle, torch.cuda.current_stream().cuda_stream, int(reps), out, self.n_ops), "stv_program_profile_reps"))
         return list(out)
 
     def __del__(self) -> None:

@@ -103,13 +103,23 @@ class GoldenCase:
         assert bool(self.arrays["x0_is_content"])
         return self.images()[0].clone()
 
-    def step_tolerances(self) -> tuple[np.ndarray, np.ndarray]:
+    def spread_level(self, grad_dev_rms: float = 0.0) -> int:
+        """Index into the fixture's perturbation levels (``sens_eps``: 3e-7 = two fp32 ulps, 3e-6, 3e-5): the smallest
+        level that is at least ``grad_dev_rms`` - the measured relative rms distance of a path's step-1 gradient from the
+        reference's.  An implementation that sums a convolution's 9*Cin products in another order is not the reference's
+        kernels re-run with another thread count: its trajectory may spread like the reference's own under gradient
+        noise of ITS size, not of 2 ulps."""
+        eps = np.asarray(self.arrays["sens_eps"], dtype=np.float64)
+        idx = int(np.searchsorted(eps, grad_dev_rms, side="left"))
+        return min(idx, len(eps) - 1)
+
+    def step_tolerances(self, level: int = 0) -> tuple[np.ndarray, np.ndarray]:
         """Large fixtures: per-step tolerance of the image (relative to its max) and of the three losses
         (relative): north_star's 1e-4 OUTRIGHT wherever the reference's own trajectory reproduces to a quarter of
-        that under 2-ulp gradient noise (measured per step by oracle/make_golden.py::trajectory_spread), otherwise
-        4x the measured spread."""
-        xs = np.asarray(self.arrays["x_steps_sensitivity"], dtype=np.float64)
-        ls = np.asarray(self.arrays["loss_sensitivity"], dtype=np.float64)
+        that under gradient noise of level ``level`` (measured per step by oracle/make_golden.py::trajectory_spread),
+        otherwise 4x the measured spread."""
+        xs = np.asarray(self.arrays["x_steps_sensitivity"], dtype=np.float64)[level]
+        ls = np.asarray(self.arrays["loss_sensitivity"], dtype=np.float64)[level]
         return np.maximum(1e-4, 4.0 * xs), np.maximum(1e-4, 4.0 * ls)
 
     def pixel_tolerance(self) -> float:

@@ -7,6 +7,8 @@ only accumulation order and the final bf16 rounding (2^-8 relative) differ.
 """
 from __future__ import annotations
 
+import functools
+
 import numpy as np
 import pytest
 import torch
@@ -163,18 +165,11 @@ def test_conv_igemm_forward(dtype, case, flags, blocked):
     assert_close(ops.from_nhwc(y), ref, dtype, 9 * cin, f"conv fwd {case} flags={flags}")
 
 
-@pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [None, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18])
-@pytest.mark.parametrize("flags", [0, ops.MASK, ops.ACCUM, ops.MASK | ops.ACCUM])
-@pytest.mark.parametrize("case", [(128, 64, 33, 70), (256, 128, 16, 40), (64, 64, 9, 33), (512, 256, 8, 8),
-                                  (96, 48, 20, 36)])   # 48 channels: not whole multi-slice stages -> general 1x1 loop
-def test_conv_igemm_dual_dgrad_plus_gram_term(dtype, cfg, flags, case, monkeypatch):
-    """out = [prev +] mask(z>0) * dgrad(dy, w) + F . S^T in one launch: the mask touches the first term only."""
-    cd, cs, H, W = case            # channels of the layer above (dy) and of this layer (output, F, S)
-    if cfg is not None:
-        if cs <= 64 and cfg in (0, 2, 18):
-            pytest.skip("128-channel tiles need more than 64 output channels")
-        monkeypatch.setenv("STV_CONV_CFG", str(cfg))
+@functools.lru_cache(maxsize=None)
+def _dual_case(dtype, flags, case):
+    """Operands (on the device) and the CPU reference of one dual-launch case: the same for every tile configuration
+    the test forces (20 of them), so they are built once - the CPU convolution was most of the test's time."""
+    cd, cs, H, W = case
     w = rnd((cd, cs, 3, 3), 71, -1, 1) * (2.0 / (9 * cd)) ** 0.5
     dy = rnd((1, cd, H, W), 72)
     z = rnd((1, cs, H, W), 73)                      # this layer's stored pre-ReLU output = F
@@ -187,11 +182,26 @@ def test_conv_igemm_dual_dgrad_plus_gram_term(dtype, cfg, flags, case, monkeypat
     first = xr.grad * ((zq > 0).float() if flags & ops.MASK else 1.0)
     second = torch.einsum("bchw,nc->bnhw", zq, sq)
     ref = first + second + (pq if flags & ops.ACCUM else 0.0)
-    out = ops.to_nhwc(prev, dtype).to(DEV)
-    wb = ops.block_weights(ops.pack_weights_bwd(w).to(dtype).to(DEV))
-    zn = ops.to_nhwc(z, dtype).to(DEV)
-    ops.conv_igemm_dual(ops.to_nhwc(dy, dtype).to(DEV), wb, zn, sq.to(dtype).to(DEV).contiguous(),
-                        ref=zn if flags & ops.MASK else None, out=out, flags=flags)
+    dev = {"prev": ops.to_nhwc(prev, dtype).to(DEV), "wb": ops.block_weights(ops.pack_weights_bwd(w).to(dtype).to(DEV)),
+           "z": ops.to_nhwc(z, dtype).to(DEV), "dy": ops.to_nhwc(dy, dtype).to(DEV), "s": sq.to(dtype).to(DEV).contiguous()}
+    return ref, dev
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [None, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18])
+@pytest.mark.parametrize("flags", [0, ops.MASK, ops.ACCUM, ops.MASK | ops.ACCUM])
+@pytest.mark.parametrize("case", [(128, 64, 33, 70), (256, 128, 16, 40), (64, 64, 9, 33), (512, 256, 8, 8),
+                                  (96, 48, 20, 36)])   # 48 channels: not whole multi-slice stages -> general 1x1 loop
+def test_conv_igemm_dual_dgrad_plus_gram_term(dtype, cfg, flags, case, monkeypatch):
+    """out = [prev +] mask(z>0) * dgrad(dy, w) + F . S^T in one launch: the mask touches the first term only."""
+    cd, cs, H, W = case            # channels of the layer above (dy) and of this layer (output, F, S)
+    if cfg is not None:
+        if cs <= 64 and cfg in (0, 2, 18):
+            pytest.skip("128-channel tiles need more than 64 output channels")
+        monkeypatch.setenv("STV_CONV_CFG", str(cfg))
+    ref, dev = _dual_case(dtype, flags, case)
+    out = dev["prev"].clone()
+    ops.conv_igemm_dual(dev["dy"], dev["wb"], dev["z"], dev["s"], ref=dev["z"] if flags & ops.MASK else None, out=out, flags=flags)
     assert_close(ops.from_nhwc(out), ref, dtype, 9 * cd + cs, f"dual {case} flags={flags}")
 
 
@@ -419,6 +429,91 @@ def test_conv_xshare_changes_nothing(dtype, case, monkeypatch):
         monkeypatch.setenv("STV_CONV_XSHARE", str(g))
         got = both()
         assert torch.equal(got[0], base[0]) and torch.equal(got[1], base[1]), f"xshare {g} {case}"
+
+
+@pytest.fixture
+def xk_workspace(monkeypatch):
+    """K split across workgroups switched on for the test, with its scratch (stv_conv_workspace)."""
+    monkeypatch.setenv("STV_CONV_XK", "1")
+    ws = torch.zeros(ops.conv_workspace_bytes(), dtype=torch.uint8, device=DEV)
+    ops.set_conv_workspace(ws)
+    yield ws
+    ops.set_conv_workspace(None)
+
+
+@pytest.mark.parametrize("case", [(512, 512, 64, 64), (512, 448, 40, 96), (256, 512, 61, 64), (512, 384, 64, 64)])
+def test_conv_split_k_across_workgroups(case, xk_workspace, monkeypatch):
+    """ConvArgs::xk (STV_CONV_XK=1): two workgroups per output tile, each on half of K, the later one adds the other's fp32
+    partial sums and runs the epilogue - every epilogue of the general kernel behind it (bias + ReLU, mask + accumulate, the
+    fused 1x1 Gram term, the max-pool + arg-max map, the routed pooling backward), ragged tiles, a tile count that is not
+    a multiple of eight (padding blocks) - against the CPU reference; the same bits on every run (a + b == b + a:
+    whichever half finishes first); the scratch words are zero again after every launch; and the plain kernel for
+    comparison (another summation order: same tolerance, not the same bits)."""
+    cin, cout, H, W = case
+    dtype = torch.bfloat16
+    ws = xk_workspace
+    x = rnd((1, cin, H, W), 151)
+    w = rnd((cout, cin, 3, 3), 152, -1, 1) * (2.0 / (9 * cin)) ** 0.5
+    b = rnd((cout,), 153, -0.2, 0.2)
+    z = rnd((1, cout, H, W), 154)
+    prev = rnd((1, cout, H, W), 155)
+    xd, bd = ops.to_nhwc(x, dtype).to(DEV), b.to(DEV)
+    wp = ops.block_weights(ops.pack_weights_fwd(w).to(dtype).to(DEV))
+    zd, pd = ops.to_nhwc(z, dtype).to(DEV), ops.to_nhwc(prev, dtype).to(DEV)
+
+    def clean():
+        torch.cuda.synchronize()
+        assert int(ws[:65536].max()) == 0, "tickets / flags not reset"
+    # forward: bias + ReLU in and out
+    ref = F.relu(F.conv2d(F.relu(q(x, dtype)), q(w, dtype), b, padding=1))
+    y1 = ops.conv_igemm(xd, wp, bd, flags=ops.RELU_IN | ops.RELU_OUT).clone()
+    clean()
+    assert_close(ops.from_nhwc(y1), ref, dtype, 9 * cin, f"xk fwd {case}")
+    for _ in range(3):
+        assert torch.equal(ops.conv_igemm(xd, wp, bd, flags=ops.RELU_IN | ops.RELU_OUT), y1), "not reproducible"
+    monkeypatch.setenv("STV_CONV_XK", "0")
+    y0 = ops.conv_igemm(xd, wp, bd, flags=ops.RELU_IN | ops.RELU_OUT)
+    monkeypatch.setenv("STV_CONV_XK", "1")
+    assert_close(ops.from_nhwc(y0), ref, dtype, 9 * cin, f"plain fwd {case}")
+    assert not torch.equal(y0, y1) or cin < 256, "the K split did not engage (same bits as the plain kernel)"
+    # mask + accumulate (a dgrad's epilogue)
+    ref2 = F.conv2d(q(x, dtype), q(w, dtype), None, padding=1) * (q(z, dtype) > 0).float() + q(prev, dtype)
+    out = pd.clone()
+    ops.conv_igemm(xd, wp, None, ref=zd, out=out, flags=ops.MASK | ops.ACCUM)
+    clean()
+    assert_close(ops.from_nhwc(out), ref2, dtype, 9 * cin, f"xk mask+accum {case}")
+    # fused max-pool + arg-max map (even sizes only)
+    if H % 2 == 0 and W % 2 == 0:
+        idx = torch.full((H // 2, W // 2, cout), 255, device=DEV, dtype=torch.uint8)
+        y, yp = ops.conv_igemm_pool(xd, wp, bd, flags=ops.RELU_OUT, pool_idx=idx)
+        clean()
+        refp = F.relu(F.conv2d(q(x, dtype), q(w, dtype), b, padding=1))
+        assert_close(ops.from_nhwc(y), refp, dtype, 9 * cin, f"xk conv+pool {case}")
+        assert torch.equal(ops.from_nhwc(yp).cpu(), F.max_pool2d(ops.from_nhwc(y).cpu(), 2, 2))
+        assert int(idx.max()) <= 7
+    # the dgrad with the Gram-backward 1x1 term of its output: dy has `cin` channels (the layer above), the output,
+    # F = z and S have `cout` (this layer) - as in test_conv_igemm_dual_dgrad_plus_gram_term
+    wd = rnd((cin, cout, 3, 3), 157, -1, 1) * (2.0 / (9 * cin)) ** 0.5
+    s_mat = rnd((cout, cout), 156, -0.02, 0.02)
+    sq = q((s_mat + s_mat.t()) * 0.5, dtype)
+    xr = torch.zeros(1, cout, H, W, requires_grad=True)
+    F.conv2d(xr, q(wd, dtype), None, padding=1).backward(q(x, dtype))
+    ref3 = xr.grad * (q(z, dtype) > 0).float() + torch.einsum("bchw,nc->bnhw", q(z, dtype), sq)
+    wb = ops.block_weights(ops.pack_weights_bwd(wd).to(dtype).to(DEV))
+    out3 = torch.empty_like(zd)
+    ops.conv_igemm_dual(xd, wb, zd, sq.to(dtype).to(DEV).contiguous(), ref=zd, out=out3, flags=ops.MASK)
+    clean()
+    assert_close(ops.from_nhwc(out3), ref3, dtype, 9 * cin + cout, f"xk dual {case}")
+    # the routed pooling backward in the epilogue (a dgrad in front of a max-pool): against the plain kernel's routing of
+    # the same sums rounded the same way is not available (another summation order), so against dgrad-then-pool-backward
+    if H % 2 == 0 and W % 2 == 0 and 4 * H * W * cout * 2 < 2 ** 31:
+        idx = torch.from_numpy((synthetic.hash_uniform(158, 3, H * W * cout) * 8).astype(np.uint8).reshape(H, W, cout)).to(DEV)
+        routed = ops.conv_igemm_route(xd, wp, idx, flags=ops.MASK)
+        clean()
+        plain = ops.conv_igemm(xd, wp, None, flags=0)            # the same sums (K split as well), unrouted
+        want = torch.zeros(2 * H, 2 * W, cout, device=DEV, dtype=dtype)
+        ops.maxpool_bwd_idx(idx, plain, 2 * H, 2 * W, out=want, flags=ops.MASK)
+        assert torch.equal(routed, want), f"xk route {case}"
 
 
 @pytest.mark.parametrize("hint_bytes", [1, 100, 4096, 1 << 20, 5 << 20])

@@ -154,6 +154,15 @@ def test_oracle_matches_large_reference_fixture(name):
             worst_x = max(worst_x, dev)
             assert dev <= xtol[s_i], f"{name}: image after step {s_i + 1} differs by {dev:.2e} of its range"
             assert float(x_s.double().abs().sum()) == pytest.approx(float(case.arrays["x_steps_abs_sum"][s_i]), rel=xtol[s_i])
+    for k_full in m["full_steps"]:          # the full images from inside the trajectory, and the gradient the next step saw there
+        want = case.arrays[f"x_after_step_{k_full}"]
+        dev = float(np.abs(res["x_steps"][k_full - 1].numpy() - want).max() / float(np.abs(want).max()))
+        worst_x = max(worst_x, dev)
+        assert dev <= xtol[k_full - 1]
+        g_here = ocm.loss_and_grad(model, torch.from_numpy(want), m["style_w"], m["content_w"])
+        assert float(g_here[2]) == pytest.approx(float(case.arrays["total_loss"][k_full]), rel=RTOL)
+        np.testing.assert_allclose(g_here[3].numpy()[..., ::k, ::k], case.arrays[f"grad_at_step_{k_full + 1}_sub"], rtol=1e-4,
+                                   atol=1e-6 * float(case.arrays[f"grad_at_step_{k_full + 1}_absmax"]))
     xf = res["x"].numpy()
     dev = float(np.abs(xf[..., ::k, ::k] - case.arrays["x_final_sub"]).max() / float(case.arrays["x_final_absmax"]))
     worst_x = max(worst_x, dev)
