@@ -47,7 +47,11 @@
 #define STV_WS_F_AUX 0       // ... of the z-tile DMA (backward form: last use of that map in the step)
 #endif
 #ifndef STV_WS_SWEEP
-#define STV_WS_SWEEP 1       // forward form behind a ReLU: clamp the staged halo tile ONCE in LDS (0: every A fragment after its read)
+// Forward form behind a ReLU: 1 = clamp the staged halo tile ONCE in LDS (a sweep under the previous tile's MFMAs),
+// 0 = every A fragment after its read.  Measured (round 5, profiles/r05_ws_sweep_ab.log): the sweep is 1-3 % SLOWER -
+// isolated 116.5-118.2 against 114.8 us, step 2.599 against 2.562-2.607 ms at 1024^2 - so the default stays 0
+// (profiles/EXPERIMENTS.md 3.9); the sweep is kept for A/B builds (tools/build_variant.sh).
+#define STV_WS_SWEEP 0
 #endif
 #ifndef STV_WS128_DEFAULT
 #define STV_WS128_DEFAULT 1  // the 128 -> 128 layer on this kernel unless STV_CONV_WS128=0
@@ -473,7 +477,9 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgrou
     // The previous tile's deferred stores count too: they can only make the wait longer, never satisfied
     // early (the threshold is exactly the newest DMA's size).
     const bool more = t + NB * tstride < ntiles && !(diag & 2);
-    if (!sweep && NB == 3 && t + 2 * tstride < ntiles && !(diag & 2)) wait_vmcnt<kTileOps>();
+    // (STV_WS_SWEEP=2, diagnostic build: the sweep with the counted wait - NOT guaranteed to have the swept tile landed;
+    //  isolates what the full drain costs)
+    if ((!sweep || STV_WS_SWEEP == 2) && NB == 3 && t + 2 * tstride < ntiles && !(diag & 2)) wait_vmcnt<kTileOps>();
     else wait_vmcnt<0>();
     if constexpr (sweep) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the next tile's sweep: its writes were issued columns ago
     __builtin_amdgcn_s_barrier();

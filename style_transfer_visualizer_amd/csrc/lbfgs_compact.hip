@@ -302,7 +302,8 @@ __global__ __launch_bounds__(256) void solve_kernel(CState* st, CWs w, int hist,
   __shared__ int sh_skip, sh_pushed, sh_m, sh_head, sh_cslot, sh_mold;
   __shared__ float sh_newro, sh_H;
   __shared__ double sh_gs[MAX_S], sh_gy[MAX_S], sh_ro[MAX_S];
-  __shared__ double sh_bp[4][128];       // per-wave partial sums of the second walk
+  __shared__ double sh_bp[2][128];       // partial sums of the second walk (indices below / from 64)
+  __shared__ double sh_cy[128];          // the final y-coefficients, for every thread of the second walk
   const int tid = threadIdx.x;
   const double* D = w.dots;
   const double* SC = w.dots + 5 * MAX_HIST;
@@ -401,7 +402,7 @@ __global__ __launch_bounds__(256) void solve_kernel(CState* st, CWs w, int hist,
     if (j < m) {
       int col = head + j;
       if (col >= S) col -= S;
-      constexpr int FB = 25;                   // rows per batch: FB loads in flight, then the stores
+      constexpr int FB = 50;                   // rows per batch: FB loads in flight, then the stores (history 100: ONE batch per thread)
       for (int ib = i0; ib < m; ib += 2 * FB) {
         double v[FB];
 #pragma unroll
@@ -504,49 +505,49 @@ __global__ __launch_bounds__(256) void solve_kernel(CState* st, CWs w, int hist,
   SOLVE_STAMP(4);
   const double H = (double)sh_H;
   cg *= H; cy0 *= H; cy1 *= H;
-  // walk 2: b_own = cg*(g.y_own) + sum_j cy_j * YY[own][j]  (no recursion: cy is final)
+  // walk 2: b_own = cg*(g.y_own) + sum_j cy_j * YY[own][j]  (no recursion: cy is final) - a plain symmetric matrix-vector
+  // product.  Round 5: all 256 threads take part - thread (row = tid & 127, part = tid >> 7) sums its row over two
+  // 32-index chunks with every LDS read independent of the others (the per-wave form walked its 32 indices with a
+  // broadcast per index: 4.0 us of the kernel's 23.4 by the phase stamps, tools/solve_stamps.py).  Same chunks, same order
+  // inside a chunk, same grouping of the four chunk sums as before: the coefficients are bit-identical.
   double b0 = cg * gy0, b1 = cg * gy1;
-  auto walk2 = [&](auto HI, int jfrom, int jto) {       // j = jfrom .. jto-1
-    constexpr bool hi = decltype(HI)::value;
-    if (jfrom >= jto) return;
-    double n0[CH], n1[CH];
-    auto fetch = [&](int jb) {                 // y_own . y_j: stored at [max(own, j)][min(own, j)]
+  {
+    if (wave4 == 0) {
+      sh_cy[j0] = cy0;
+      sh_cy[j1] = cy1;
+    }
+    __syncthreads();
+    const int row = tid & 127, part = tid >> 7;
+    double chunk_sum[2] = {0.0, 0.0};
+    if (row < m) {
+      const int rb = row * P;
 #pragma unroll
-      for (int k = 0; k < CH; ++k) {
-        const int j = min(jb + k, m - 1);
-        n0[k] = sT[(j <= q0) ? r0 + j : j * P + q0];
-        n1[k] = sT[(j <= q1) ? r1 + j : j * P + q1];
-      }
-    };
-    fetch(jfrom);
-    for (int jb = jfrom; jb < jto; jb += CH) {
-      double c0[CH], c1[CH];
+      for (int c = 0; c < 2; ++c) {
+        const int jb = (2 * part + c) * 32;
+        double acc = 0.0;
+        // sixteen table entries and coefficients in flight, then their FMAs in index order: no branch inside (an index
+        // past the history reads a valid entry against a coefficient that is zero: acc + 0 == acc)
 #pragma unroll
-      for (int k = 0; k < CH; ++k) { c0[k] = n0[k]; c1[k] = n1[k]; }
-      if (jb + CH < jto) fetch(jb + CH);
+        for (int kb = 0; kb < 32; kb += 16) {
+          double cv[16], tv[16];
 #pragma unroll
-      for (int k = 0; k < CH; ++k) {
-        const int j = jb + k;
-        if (j >= jto) break;
-        const double cyj = bcast(hi ? cy1 : cy0, hi ? j - 64 : j);
-        b0 += cyj * c0[k];
-        b1 += cyj * c1[k];
+          for (int k = 0; k < 16; ++k) {
+            const int j = jb + kb + k;
+            const int jc = j < m ? j : m - 1;
+            cv[k] = sh_cy[j];
+            tv[k] = sT[(jc <= row) ? rb + jc : jc * P + row];     // y_row . y_j: stored at [max][min]
+          }
+#pragma unroll
+          for (int k = 0; k < 16; ++k) acc = fma(cv[k], tv[k], acc);
+        }
+        chunk_sum[c] = acc;
       }
     }
-  };
-  {
-    // wave w takes j in [32w, 32w + 32): slot 0 owners for w < 2, slot 1 owners above
-    const double init0 = b0, init1 = b1;
-    b0 = 0.0; b1 = 0.0;
-    const int jb = wave4 * 32, je = m < jb + 32 ? m : jb + 32;
-    if (wave4 < 2) walk2(lo_t{}, jb, je);
-    else walk2(hi_t{}, jb, je);
-    sh_bp[wave4][lane] = b0;
-    sh_bp[wave4][64 + lane] = b1;
+    sh_bp[part][row] = chunk_sum[0] + chunk_sum[1];
     __syncthreads();
     if (tid >= 64) return;
-    b0 = init0 + ((sh_bp[0][lane] + sh_bp[1][lane]) + (sh_bp[2][lane] + sh_bp[3][lane]));
-    b1 = init1 + ((sh_bp[0][64 + lane] + sh_bp[1][64 + lane]) + (sh_bp[2][64 + lane] + sh_bp[3][64 + lane]));
+    b0 = b0 + (sh_bp[0][lane] + sh_bp[1][lane]);
+    b1 = b1 + (sh_bp[0][64 + lane] + sh_bp[1][64 + lane]);
   }
   SOLVE_STAMP(5);
   // walk 3, i = 0 .. m-1:  cs_i = al_i - ro_i * b_i,  b_own += cs_i * SY[i][own]  (own newer than i)
