@@ -9,9 +9,9 @@ synthetic weights seed 0, content seed 0, style seed 1, ``init_method=random`` o
 weights.  What is asserted:
 
 * integer bookkeeping, bit-exact: step ids 1..N, one closure per step, history length, the logging steps;
-* every 100 steps the CPU oracle - rounding to bf16 exactly where the kernels do - is
-  evaluated AT THE IMAGE THE HIP PATH HOLDS and must give the loss the HIP path logged for it (chaos-free:
-  nothing is compared between two free-running trajectories);
+* every 100 steps (512^2; at 1024^2, where one oracle pass in bf16 rounding is 9 s of host time, at the image the LAST step
+  evaluates) the CPU oracle - rounding to bf16 exactly where the kernels do - is evaluated AT THE IMAGE THE HIP PATH HOLDS and
+  must give the loss the HIP path logged for it (chaos-free: nothing is compared between two free-running trajectories);
 * the device L-BFGS state (``n_iter``, history length, skip / no-update flags) equals, at each of the first 110
   steps, that of an ``oracle.optim_ref.LbfgsRef`` twin fed the same gradients: the ramp to 100 pairs, the first
   ten evictions (1024^2: the twin runs in float64 on the device); at the end ``hist_len == 100`` and ``n_iter == steps``;
@@ -58,7 +58,7 @@ class _Bar:
         return None
 
 
-@pytest.mark.parametrize("size,steps,every,precision", [(512, 300, 100, "bf16"), (512, 300, 100, "fp32"), (1024, 500, 250, "bf16")])
+@pytest.mark.parametrize("size,steps,every,precision", [(512, 300, 100, "bf16"), (512, 300, 100, "fp32"), (1024, 500, 500, "bf16")])
 def test_config_runs_at_full_length(size, steps, every, precision, monkeypatch):
     monkeypatch.setenv("STV_SYNTHETIC_WEIGHTS", "0")
     bf16 = precision == "bf16"

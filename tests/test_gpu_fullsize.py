@@ -5,7 +5,7 @@ weights - what only exists at full size (the tile configurations picked there, G
 
 Per size and precision: the five Gram targets, then one closure + three L-BFGS steps with the CPU
 oracle re-evaluated AT THE SAME IMAGE (chaos-free: reference optimization.py:286-327,
-core_model.py:297-328) - at every step at 512^2, at the first and the last evaluation at 1024^2 - and at every step
+core_model.py:297-328) - at the first and the last evaluation - and at every step
 the device L-BFGS update against the oracle optimizer fed the same gradients.  Float64 evaluations (5 s at 512^2,
 20-25 s at 1024^2 each) are spent where they carry information.  At the START image the float64 gradient is a property of
 the oracle and the seeded inputs alone: it is computed once (oracle/make_fullsize_ref.py -> tests/golden/
