@@ -365,6 +365,48 @@ def _c4_strip_worker(rank: int, world: int, port: int, out_dir: str, q) -> None:
     dist.destroy_process_group()
 
 
+def _c4_start(out_dir) -> dict:
+    """Start the four strip ranks of configs[4] and the CPU oracle beside them; returns the handles the test collects."""
+    import threading
+    world = 4
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    job = {"t0": time.time(), "q": q, "world": world, "dir": out_dir, "oracle_out": {}}
+    job["procs"] = [ctx.Process(target=_c4_strip_worker, args=(r, world, port, str(out_dir), q)) for r in range(world)]
+    for p in job["procs"]:
+        p.start()
+
+    # The CPU oracle (its content target at 4K and one forward pass per marked image, ~12-25 s each) works on the host
+    # cores WHILE the strips run on the GPU: a thread picks each gathered image up as soon as rank 0 has written it.
+    oracle_out = job["oracle_out"]
+
+    def _oracle_thread():
+        try:
+            t_start = time.time()
+            content_c, style_c = synthetic.synthetic_image(0, C4_H, C4_W), synthetic.synthetic_image(1, 512, 512)
+            oracle = ocm.OracleModel(ocm.vgg_program(synthetic.synthetic_conv_weights(0), synthetic.VGG19_CFG), S_LAYERS, C_LAYERS)
+            oracle.set_targets(style_c, content_c)
+            for k in C4_ORACLE_MARKS:
+                path = out_dir / f"image_{k}.npy"
+                while not path.exists():
+                    if time.time() - t_start > 900:
+                        raise TimeoutError(f"no gathered image for step {k}")
+                    time.sleep(0.25)
+                img = torch.from_numpy(np.load(path))
+                with torch.no_grad():
+                    s_l, c_l = oracle(img)
+                oracle_out[k] = (float(torch.stack(s_l).sum()), float(torch.stack(c_l).sum()))
+            oracle_out["seconds"] = time.time() - t_start
+        except BaseException as exc:            # surfaced by the main thread
+            oracle_out["error"] = exc
+    job["oracle_job"] = threading.Thread(target=_oracle_thread, daemon=True)
+    job["oracle_job"].start()
+    return job
+
+
 def test_configs4_200_adam_steps(tmp_path, monkeypatch):
     """BASELINE.json configs[4] at its real length: ONE 3840x2160 image, 200 Adam steps (lr 1e-3; the injected-optimizer
     path of the reference, optimization.py:104-125 / tests/test_optimization.py:178), (a) as FOUR row strips
@@ -386,43 +428,10 @@ def test_configs4_200_adam_steps(tmp_path, monkeypatch):
     case = "configs[4] 3840x2160 x200 Adam"
     world = 4
     assert [spatial.strip_rows(C4_H, r, world)[:2] for r in range(world)] == [(0, 544), (544, 1088), (1088, 1632), (1632, 2160)]
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    t0 = time.time()
-    procs = [ctx.Process(target=_c4_strip_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
-    for p in procs:
-        p.start()
-
-    # The CPU oracle (its content target at 4K and one forward pass per marked image, ~12 s each) works on the host
-    # cores WHILE the strips run on the GPU: a thread picks each gathered image up as soon as rank 0 has written it.
-    oracle_out: dict = {}
-
-    def _oracle_thread():
-        try:
-            t_start = time.time()
-            content_c, style_c = synthetic.synthetic_image(0, C4_H, C4_W), synthetic.synthetic_image(1, 512, 512)
-            oracle = ocm.OracleModel(ocm.vgg_program(synthetic.synthetic_conv_weights(0), synthetic.VGG19_CFG), S_LAYERS, C_LAYERS)
-            oracle.set_targets(style_c, content_c)
-            for k in C4_ORACLE_MARKS:
-                path = tmp_path / f"image_{k}.npy"
-                while not path.exists():
-                    if time.time() - t_start > 900:
-                        raise TimeoutError(f"no gathered image for step {k}")
-                    time.sleep(0.25)
-                img = torch.from_numpy(np.load(path))
-                with torch.no_grad():
-                    s_l, c_l = oracle(img)
-                oracle_out[k] = (float(torch.stack(s_l).sum()), float(torch.stack(c_l).sum()))
-            oracle_out["seconds"] = time.time() - t_start
-        except BaseException as exc:            # surfaced by the main thread
-            oracle_out["error"] = exc
-
-    import threading
-    oracle_job = threading.Thread(target=_oracle_thread, daemon=True)
-    oracle_job.start()
+    # (round 5 also tried starting the ranks with the MODULE, beside the configs[1] / [2] / [0] runs: this test 71 -> 44 s, the
+    #  others slower by as much - five processes and the oracle share the host cores; 362 against 365 s for the suite: not kept)
+    job = _c4_start(tmp_path)
+    tmp_path, q, procs, oracle_out, oracle_job, t0 = job["dir"], job["q"], job["procs"], job["oracle_out"], job["oracle_job"], job["t0"]
     got = dict(q.get(timeout=800) for _ in range(world))
     for p in procs:
         p.join(timeout=120)
