@@ -53,6 +53,9 @@
 // (profiles/EXPERIMENTS.md 3.9); the sweep is kept for A/B builds (tools/build_variant.sh).
 #define STV_WS_SWEEP 0
 #endif
+#ifndef STV_WS_W_AGPR
+#define STV_WS_W_AGPR 1      // resident weights pinned to AGPRs (0: wherever the register allocator puts them)
+#endif
 #ifndef STV_WS128_DEFAULT
 #define STV_WS128_DEFAULT 1  // the 128 -> 128 layer on this kernel unless STV_CONV_WS128=0
 #endif
@@ -153,6 +156,16 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int n_workgrou
         const int elem = w_blocked ? (((tap * NSTAGE + s) * a.cout + n) * CK + h * 8) : ((tap * a.cout + n) * CIN + s * CK + h * 8);
         wreg[s][tap] = __builtin_bit_cast(bf16x8v, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (uint32_t)(elem * 2), 0, 0));
       }
+#if STV_WS_W_AGPR
+    // The resident weights are MFMA operands only: pinned to the accumulation half of the register file.  Left to the
+    // allocator they are loaded as ordinary VGPR values, spilled to AGPRs under the pressure of a 476-register kernel and
+    // copied back - four v_accvgpr_read_b32 in front of every group of four MFMAs, 144-227 per tile (round 5, read off
+    // the ISA) - although the matrix instruction can read an AGPR operand directly.
+#pragma unroll
+    for (int s = 0; s < NSTAGE; ++s)
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) asm volatile("" : "+a"(wreg[s][tap]));
+#endif
   }
   bf16x8v sreg[DG && DUAL ? FSTAGES : 1];          // DG with a fused 1x1 term: S rows of this wave's channels (plain [cout][cout])
   constexpr bool dual = DG && DUAL;                // (compile-time, like POOL: no branch between MFMA groups)
