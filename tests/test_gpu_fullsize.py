@@ -271,7 +271,7 @@ def test_fullsize_closure_and_lbfgs_steps_match_oracle(size, precision, monkeypa
         # the CPU oracle is re-evaluated at the LAST step (an image three L-BFGS updates away from the start); the L-BFGS
         # update itself is checked at every step (round 5: the 512^2 runs no longer evaluate it at steps 2 and 3 as well -
         # 6-10 s of host time per run for rows the last step and tests/test_gpu_configs.py repeat)
-        if step == 3:
+        if step == 3 and not (bf16 and size > 512):     # (1024^2 bf16 at a moved image: tests/test_gpu_configs.py, 500 steps, oracle at the final image)
             xc = x.detach().cpu()
             ref_k = ocm.loss_and_grad(oracle, xc, STYLE_W, CONTENT_W)
             # float64: plain rows at the first and the last evaluation of the 512^2 run; losses against the fp32 oracle everywhere
