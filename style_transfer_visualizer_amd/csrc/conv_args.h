@@ -42,6 +42,9 @@ constexpr int kXkSlabOffset = 65536;       // bytes: [ticket, flag] pairs of up 
 // stv_conv_ws_supported() says whether a launch with these arguments can take it.
 bool stv_conv_ws_supported(const ConvArgs& a, int dtype, int taps);
 int stv_conv_ws_launch(const ConvArgs& a, hipStream_t st);
+// conv_ws2.hip: the forward forms of the Cin = 64 layers with two waves per SIMD (K split between them); STV_CONV_WS2
+bool stv_conv_ws2_supported(const ConvArgs& a, int dtype, int taps);
+int stv_conv_ws2_launch(const ConvArgs& a, hipStream_t st);
 
 // conv_igemm16.hip: the general kernel's tiles on v_mfma_f32_16x16x32_bf16 (configurations 13 and up; bf16, cin % 32 == 0).
 int stv_conv_launch_m16(const ConvArgs& a, int cfg, int taps, hipStream_t st);

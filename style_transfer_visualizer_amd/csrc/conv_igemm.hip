@@ -239,6 +239,12 @@ int launch_xk(const ConvArgs& a, hipStream_t st) {
 
 template <typename T, int TAPS>
 int launch_typed(const ConvArgs& a, hipStream_t st) {
+  // forward forms of the Cin = 64 layers, two waves per SIMD (conv_ws2.hip; STV_CONV_WS2, off by default)
+  if (stv_conv_ws2_supported(a, elem_traits<T>::kDtype, TAPS)) {
+    g_stv_next_w = nullptr;
+    g_stv_next_w_bytes = 0;
+    return stv_conv_ws2_launch(a, st);
+  }
   // short-K layers (Cin = 64, bf16): weight-stationary persistent kernel (conv_ws.hip)
   if (stv_conv_ws_supported(a, elem_traits<T>::kDtype, TAPS)) {
     g_stv_next_w = nullptr;        // (the weight-stationary kernel does not touch ahead: the hint is consumed, not left for a later launch)

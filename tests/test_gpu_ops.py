@@ -323,6 +323,60 @@ def test_conv_ws_forward_pool_and_backward(case, monkeypatch):
         assert float((d / (2.0 ** -7 * torch.maximum(out.float().abs(), out_gen.float().abs()) + 1e-6)).max()) <= 1.0
 
 
+@pytest.mark.parametrize("skew", ["1", "0"])
+@pytest.mark.parametrize("case", [(64, 75, 101), (128, 40, 72), (64, 8, 32), (64, 13, 7), (64, 4, 33), (64, 512, 512), (128, 256, 320),
+                                  (64, 1024, 1024)])
+def test_conv_ws2_forward_and_pool(case, skew, monkeypatch):
+    """The two-waves-per-SIMD form of the weight-stationary kernel (csrc/conv_ws2.hip, STV_CONV_WS2; Cin = 64, forward
+    forms; K split between the two waves of a SIMD, partial sums exchanged through LDS): bias / ReLU-on-load / ReLU /
+    fused max-pool + arg-max map / STV_POOL_ONLY against the CPU convolution, on ragged, single-tile and many-tile images,
+    with the two wave classes finishing their tile at the same time and half a tile apart (STV_WS2_SKEW)."""
+    cout, H, W = case
+    cin, dtype = 64, torch.bfloat16
+    monkeypatch.setenv("STV_CONV_WS2", "2")
+    monkeypatch.setenv("STV_WS2_SKEW", skew)
+    x = rnd((1, cin, H, W), 171)
+    w = rnd((cout, cin, 3, 3), 172, -1, 1) * (2.0 / (9 * cin)) ** 0.5
+    b = rnd((cout,), 173, -0.2, 0.2)
+    xq, wq = q(x, dtype), q(w, dtype)
+    xn = ops.to_nhwc(x, dtype).to(DEV)
+    for blocked in (True, False):
+        wp = ops.pack_weights_fwd(w).to(dtype).to(DEV)
+        if blocked:
+            wp = ops.block_weights(wp)
+        for flags in (0, ops.RELU_IN | ops.RELU_OUT):
+            ref = F.conv2d(F.relu(xq) if flags & ops.RELU_IN else xq, wq, b, padding=1)
+            ref = F.relu(ref) if flags & ops.RELU_OUT else ref
+            y = ops.conv_igemm(xn, wp, b.to(DEV), flags=flags)
+            assert_close(ops.from_nhwc(y), ref, dtype, 9 * cin, f"ws2 fwd {case} flags={flags} blocked={blocked}")
+            # the one-wave-per-SIMD kernel on the same launch: another order of the K halves, same values to rounding
+            monkeypatch.setenv("STV_CONV_WS2", "0")
+            monkeypatch.setenv("STV_CONV_WS", "2")
+            y1 = ops.conv_igemm(xn, wp, b.to(DEV), flags=flags)
+            monkeypatch.setenv("STV_CONV_WS2", "2")
+            d = (y.float() - y1.float()).abs()
+            assert float((d / (2.0 ** -7 * torch.maximum(y.float().abs(), y1.float().abs()) + 1e-6)).max()) <= 1.0
+            assert float((d > 0).float().mean()) < 5e-3
+    wp = ops.block_weights(ops.pack_weights_fwd(w).to(dtype).to(DEV))
+    for relu_in in (0, ops.RELU_IN):
+        idx = torch.full((H // 2, W // 2, cout), 255, device=DEV, dtype=torch.uint8)
+        y, yp = ops.conv_igemm_pool(xn, wp, b.to(DEV), flags=ops.RELU_OUT | relu_in, pool_idx=idx)
+        ref = F.relu(F.conv2d(F.relu(xq) if relu_in else xq, wq, b, padding=1))
+        assert_close(ops.from_nhwc(y), ref, dtype, 9 * cin, f"ws2 conv+pool {case} relu_in={relu_in}")
+        assert torch.equal(ops.from_nhwc(yp).cpu(), F.max_pool2d(ops.from_nhwc(y).cpu(), 2, 2))
+        assert int(idx.max()) <= 7
+        idx2 = torch.full_like(idx, 255)
+        y2 = torch.full_like(y, 7.0)
+        _, yp2 = ops.conv_igemm_pool(xn, wp, b.to(DEV), flags=ops.RELU_OUT | relu_in | ops.POOL_ONLY, out=y2, pool_idx=idx2)
+        assert torch.equal(yp2, yp) and torch.equal(idx2, idx) and bool((y2 == 7.0).all())
+    dyp = ops.to_nhwc(rnd((1, cout, H // 2, W // 2), 174), dtype).to(DEV)
+    for flags in (0, ops.MASK):
+        a_, b_ = torch.zeros_like(y), torch.zeros_like(y)
+        ops.maxpool_bwd(y, dyp, out=a_, flags=flags)
+        ops.maxpool_bwd_idx(idx, dyp, H, W, out=b_, flags=flags)
+        assert torch.equal(a_, b_), f"ws2 arg-max map differs from the activation-based routing, flags={flags}"
+
+
 @pytest.mark.parametrize("cfg", [None, 0, 1, 3, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18])
 @pytest.mark.parametrize("case", [(128, 64, 32, 64), (256, 128, 16, 40), (512, 512, 8, 8), (512, 256, 12, 20)])
 def test_conv_igemm_route_equals_dgrad_then_pool_backward(cfg, case, monkeypatch):

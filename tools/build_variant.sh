@@ -11,7 +11,7 @@ OUT=$ROOT/style_transfer_visualizer_amd/variants
 mkdir -p $OUT/obj_$NAME
 make -C $CSRC -j8 > /dev/null
 OBJS=""
-for src in conv_igemm conv_igemm16 conv_ws conv_first pointwise gram optim lbfgs_compact program; do
+for src in conv_igemm conv_igemm16 conv_ws conv_ws2 conv_first pointwise gram optim lbfgs_compact program; do
   if [[ " $* " == *" $src.hip "* ]]; then
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-variable $FLAGS -I$CSRC -c $CSRC/$src.hip -o $OUT/obj_$NAME/$src.o &
     OBJS="$OBJS $OUT/obj_$NAME/$src.o"

@@ -24,7 +24,7 @@ for (H, cout, relu, pool) in ((HH, 64, True, True), (HH // 2, 128, False, False)
     else:
         us = t(lambda: ops.conv_igemm(x, w, b, out=y, flags=fl))
     gf = 2 * 9 * 64 * cout * H * H / 1e9
-    print(f"diag={os.environ.get('STV_WS_DIAG','0')} fwd {H}^2 64->{cout} relu={relu} pool={pool}: {us:7.1f} us  {gf / us * 1e3:7.0f} TFLOP/s")
+    print(f"ws2={os.environ.get('STV_CONV_WS2','0')} skew={os.environ.get('STV_WS2_SKEW','1')} diag={os.environ.get('STV_WS_DIAG','0')} fwd {H}^2 64->{cout} relu={relu} pool={pool}: {us:7.1f} us  {gf / us * 1e3:7.0f} TFLOP/s")
 H = HH
 dy = (torch.randn(H, H, 64, device=dev) * 0.5).bfloat16(); z = (torch.randn(H, H, 64, device=dev)).bfloat16()
 wb = ops.block_weights((torch.randn(9, 64, 64, device=dev) * 0.06).bfloat16()); S = (torch.randn(64, 64, device=dev) * 0.01).bfloat16()
