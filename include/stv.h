@@ -289,11 +289,18 @@ int stv_loss_combine(const float* parts, const int32_t* table, const float* scal
 /* The same, and the producer also keeps the per-step history the reference's LossAccumulator keeps on the
  * device (loss_accumulator.py:97-118: one ring slot per step): log_ring fp32 [3][log_capacity] (style, content,
  * total), log_count = evaluations so far (device counter, advanced here), slot = count % capacity.  Saves the
- * per-step copy kernel between two replays of the captured step.  log_ring and log_count both NULL: as above. */
+ * per-step copy kernel between two replays of the captured step.  log_ring and log_count both NULL: as above.
+ * log_seq (optional): the ring is HOST memory from stv_host_mailbox_alloc and *log_seq, in the same allocation, receives
+ * the record count after the record (system-scope release): the host reads a step's scores as soon as the combine kernel
+ * has run - no copy, no stream synchronisation, the rest of the step still in flight (the reference's logging point,
+ * optimization.py:375-391, blocks on .item() there). */
 int stv_loss_combine_log(const float* parts, const int32_t* table, const float* scale,
                          int n_terms, float style_w, float content_w, float* losses,
                          float* scores, float* log_ring, int log_capacity, uint32_t* log_count,
-                         void* stream);
+                         uint32_t* log_seq, void* stream);
+/* Pinned host memory, mapped under the same pointer on the device, fine-grained coherent, zeroed. */
+int stv_host_mailbox_alloc(size_t bytes, void** out);
+void stv_host_mailbox_free(void* p);
 
 /* ---- Optimizer updates (torch.optim.LBFGS.step / Adam.step driven from
  *      optimization.py:175), device resident: no host synchronisation. ----- */
@@ -335,7 +342,7 @@ enum {
   STV_OP_CONV_FIRST_FWD = 1, STV_OP_CONV_FIRST_DGRAD, STV_OP_CONV, STV_OP_POOL_FWD,
   STV_OP_POOL_BWD, STV_OP_RELU_FWD, STV_OP_RELU_BWD, STV_OP_GRAM_PARTIAL,
   STV_OP_GRAM_FINISH, STV_OP_CONTENT_LOSS, STV_OP_CONTENT_GRAD, STV_OP_LOSS_COMBINE,
-  STV_OP_MEMSET, STV_OP_GRAM_MULTI
+  STV_OP_MEMSET, STV_OP_GRAM_MULTI, STV_OP_LBFGS_STEP
 };
 /* Scheduling hints in stv_op_t.flags (masked off before the kernel sees them):
  * an op with STV_LANE_SIDE may run concurrently with the ops after it: it reads only
@@ -351,7 +358,11 @@ enum { STV_LANE_SIDE = 1 << 29, STV_LANE_JOIN = 1 << 30 };
  * GRAM_MULTI: p0 = HOST pointer to an array of stv_gram_tap_t, n = its length; the array is
  * copied into the program when it is created.
  * CONTENT_LOSS with q1 set runs stv_content_loss_grad (q1 = dF, f0 = coef).
- * LOSS_COMBINE with q2 AND q3 set runs stv_loss_combine_log (q2 = log_ring, q3 = log_count, n = log_capacity). */
+ * LOSS_COMBINE with q2 AND q3 set runs stv_loss_combine_log (q2 = log_ring, q3 = log_count, n = log_capacity, p3 = log_seq).
+ * LBFGS_STEP runs stv_lbfgsc_step as the LAST op of a step's schedule (p0 = grad, q0 = x, q1 = state, q2 = workspace,
+ * n = elements, cin = history, cout = m_max, f0 = lr, f1 = tol_grad, f2 = tol_change): closure and optimizer update are
+ * then one replayed hipGraph - the reference's optimizer.step(closure), optimization.py:186, without a graph boundary
+ * between the two. */
 typedef struct {
   int32_t op, dtype, flags, taps;
   int32_t H, W, cin, cout;

@@ -18,7 +18,7 @@ LANE_SIDE, LANE_JOIN = 1 << 29, 1 << 30          # scheduling hints of the comma
 
 (OP_CONV_FIRST_FWD, OP_CONV_FIRST_DGRAD, OP_CONV, OP_POOL_FWD, OP_POOL_BWD, OP_RELU_FWD,
  OP_RELU_BWD, OP_GRAM_PARTIAL, OP_GRAM_FINISH, OP_CONTENT_LOSS, OP_CONTENT_GRAD,
- OP_LOSS_COMBINE, OP_MEMSET, OP_GRAM_MULTI) = range(1, 15)
+ OP_LOSS_COMBINE, OP_MEMSET, OP_GRAM_MULTI, OP_LBFGS_STEP) = range(1, 16)
 
 CONTENT_LOSS_PARTS = 256
 
@@ -92,7 +92,9 @@ SIGNATURES = {
     "stv_image_to_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_int, c_void_p]),
     "stv_loss_combine": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "stv_loss_combine_log": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p,
-                                     c_int, c_void_p, c_void_p]),
+                                     c_int, c_void_p, c_void_p, c_void_p]),
+    "stv_host_mailbox_alloc": (c_int, [c_size_t, ctypes.POINTER(c_void_p)]),
+    "stv_host_mailbox_free": (None, [c_void_p]),
     "stv_lbfgs_state_bytes": (c_size_t, [c_int]),
     "stv_lbfgs_workspace_bytes": (c_size_t, [c_size_t, c_int]),
     "stv_lbfgs_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_float, c_float, c_float, c_void_p]),

@@ -369,10 +369,10 @@ class _Engine:
         return fwd + inline + batched_tail()
 
     def _combine_op(self, style_w: float, content_w: float, score_log: tuple | None = None):
-        """``score_log`` = (ring fp32 [3, capacity], device counter int32 [1]): the combine kernel also appends
-        the three scores to the caller's history ring (stv_loss_combine_log)."""
-        ring, count = score_log if score_log is not None else (None, None)
-        op = self.sched._op(op=plan.OP_LOSS_COMBINE, p0=self.parts, p1=self.table, p2=self.scale,
+        """``score_log`` = (ring fp32 [3, capacity], device counter int32 [1][, host-visible record count int32 [1]]):
+        the combine kernel also appends the three scores to the caller's history ring (stv_loss_combine_log)."""
+        ring, count, seq = (tuple(score_log) + (None,))[:3] if score_log is not None else (None, None, None)
+        op = self.sched._op(op=plan.OP_LOSS_COMBINE, p0=self.parts, p1=self.table, p2=self.scale, p3=seq,
                             q0=self.losses, q1=self.scores, q2=ring, q3=count, n=ring.shape[1] if ring is not None else 0,
                             cin=self.n_style + self.n_content, f0=style_w, f1=content_w)
         op.flags |= _lib.LANE_JOIN          # first reader of what the loss-side ops wrote
@@ -494,19 +494,32 @@ class _Engine:
 
     # -- execution -------------------------------------------------------------
     def loss_and_grad(self, x: torch.Tensor, grad: torch.Tensor, style_w: float, content_w: float, *,
-                      score_log: tuple | None = None) -> None:
+                      score_log: tuple | None = None, then_step=None) -> None:
+        """``then_step`` (an ``optimizers.StepRequest`` for ``x``): the L-BFGS update of ``x`` from ``grad`` is the
+        schedule's last op - closure and update are one launch (one hipGraph)."""
         self.generation += 1
         key = ("fused", x.data_ptr(), grad.data_ptr(), style_w, content_w,
-               None if score_log is None else (score_log[0].data_ptr(), score_log[1].data_ptr(), tuple(score_log[0].shape)))
+               None if score_log is None else (tuple(t.data_ptr() for t in score_log), tuple(score_log[0].shape)),
+               None if then_step is None else then_step.key())
 
         def build():
             s = self.sched
             s.alloc_grads()          # the content term's gradient is written during the forward half
             fused_content = tuple(t for t in s.content_taps if self._content_fused(t))
+            tail = []
+            if then_step is not None:
+                # m_max = history: the reduction's grid covers a full history from the first step on (blocks past the
+                # live pairs return at once), so ONE captured graph serves every step
+                op = s._op(op=_lib.OP_LBFGS_STEP, p0=grad, q0=x, q1=then_step.state, q2=then_step.work, n=x.numel(),
+                           cin=then_step.history, cout=then_step.history, f0=then_step.lr, f1=then_step.tol_grad,
+                           f2=then_step.tol_change)
+                op.flags |= _lib.LANE_JOIN
+                tail.append(op)
             return (self._forward_with_losses(x, style_coef=style_w, with_seed=True, content_coef=content_w)
                     + [self._combine_op(style_w, content_w, score_log)]
                     + s.backward_ops(grad, style_coef=style_w, content_coef=content_w, coef_dev=None,
-                                     prewritten=fused_content))
+                                     prewritten=fused_content)
+                    + tail)
         self._program(key, build).run(self.use_graph)
 
     def forward_losses(self, x: torch.Tensor) -> None:
@@ -671,7 +684,10 @@ class StyleContentModel(nn.Module):
         if grad is None or grad.shape != x.shape or grad.device != x.device:
             grad = torch.zeros_like(x, requires_grad=False)
             self._grad_buf = grad
-        eng.loss_and_grad(x.detach(), grad, float(style_w), float(content_w), score_log=score_log)
+        from . import optimizers  # noqa: PLC0415
+        # inside HipLBFGS.step(closure) for this very tensor: the update rides at the end of the same launch
+        eng.loss_and_grad(x.detach(), grad, float(style_w), float(content_w), score_log=score_log,
+                          then_step=optimizers.claim_step(x))
         x.grad = grad
         scores = eng.scores if live_scores else eng.scores.clone()
         return scores[0], scores[1], scores[2]

@@ -3,6 +3,8 @@
 // gradient, and the final score combine.  All activation traffic is 16-byte
 // vectors per lane (1 KiB per wave instruction); grids are capped and
 // grid-strided.
+#include <string.h>
+
 #include "stv_common.h"
 
 namespace {
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(1024) void loss_combine_kernel(const float* __restr
                                                             float style_w, float content_w,
                                                             float* __restrict__ losses, float* __restrict__ scores,
                                                             float* __restrict__ log_ring, int log_cap,
-                                                            uint32_t* __restrict__ log_count) {
+                                                            uint32_t* __restrict__ log_count, uint32_t* log_seq) {
   constexpr int MAXT = 64, NW = 16;
   __shared__ int s_off[MAXT], s_cnt[MAXT], s_kind[MAXT], s_start[MAXT + 1];
   __shared__ float s_scale[MAXT], s_term[MAXT];
@@ -402,10 +404,20 @@ __global__ __launch_bounds__(1024) void loss_combine_kernel(const float* __restr
     if (log_ring) {          // per-evaluation history kept by the producer: slot = evaluations so far (mod capacity)
       const uint32_t k = *log_count;
       const uint32_t slot = k % (uint32_t)log_cap;
-      log_ring[slot] = style;
-      log_ring[(size_t)log_cap + slot] = content;
-      log_ring[2 * (size_t)log_cap + slot] = total_loss;
-      *log_count = k + 1;
+      if (log_seq) {
+        // the ring lives in host memory the CPU reads while this step is still running: system-scope stores, then the
+        // record count with release semantics - a reader that sees count k + 1 sees record k
+        __hip_atomic_store(&log_ring[slot], style, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&log_ring[(size_t)log_cap + slot], content, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&log_ring[2 * (size_t)log_cap + slot], total_loss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        *log_count = k + 1;
+        __hip_atomic_store(log_seq, k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      } else {
+        log_ring[slot] = style;
+        log_ring[(size_t)log_cap + slot] = content;
+        log_ring[2 * (size_t)log_cap + slot] = total_loss;
+        *log_count = k + 1;
+      }
     }
   }
 }
@@ -599,19 +611,38 @@ extern "C" int stv_content_grad(const void* F, const void* target, void* dF, siz
 
 extern "C" int stv_loss_combine_log(const float* parts, const int32_t* table, const float* scale, int n_terms,
                                     float style_w, float content_w, float* losses, float* scores, float* log_ring,
-                                    int log_capacity, uint32_t* log_count, void* stream) {
+                                    int log_capacity, uint32_t* log_count, uint32_t* log_seq, void* stream) {
   if (!parts || !table || !scale || !losses || !scores || n_terms < 0) return STV_ERR_ARG;
   if (n_terms > 64) return STV_ERR_ARG;
   if ((log_ring == nullptr) != (log_count == nullptr) || (log_ring && log_capacity <= 0)) return STV_ERR_ARG;
+  if (log_seq && !log_ring) return STV_ERR_ARG;
   hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), parts,
-                     table, scale, n_terms, style_w, content_w, losses, scores, log_ring, log_capacity, log_count);
+                     table, scale, n_terms, style_w, content_w, losses, scores, log_ring, log_capacity, log_count, log_seq);
   STV_CHECK_LAUNCH();
   return STV_OK;
 }
 
+// Host memory the GPU writes while the CPU reads (the loss history of a run in flight): pinned, mapped into the device's
+// address space under the same pointer, fine-grained coherent.  Zeroed.
+extern "C" int stv_host_mailbox_alloc(size_t bytes, void** out) {
+  if (!out || bytes == 0) return STV_ERR_ARG;
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess || !p) {
+    (void)hipGetLastError();
+    return STV_ERR_ALLOC;
+  }
+  memset(p, 0, bytes);
+  *out = p;
+  return STV_OK;
+}
+
+extern "C" void stv_host_mailbox_free(void* p) {
+  if (p) (void)hipHostFree(p);
+}
+
 extern "C" int stv_loss_combine(const float* parts, const int32_t* table, const float* scale, int n_terms,
                                 float style_w, float content_w, float* losses, float* scores, void* stream) {
-  return stv_loss_combine_log(parts, table, scale, n_terms, style_w, content_w, losses, scores, nullptr, 0, nullptr, stream);
+  return stv_loss_combine_log(parts, table, scale, n_terms, style_w, content_w, losses, scores, nullptr, 0, nullptr, nullptr, stream);
 }
 
 extern "C" int stv_image_to_u8(const float* x_nchw, uint8_t* out_hwc, int H, int W, const float* mean3,

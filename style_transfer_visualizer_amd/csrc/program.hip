@@ -79,13 +79,17 @@ int run_op(const stv_op_t& op, void* st) {
                               o.dtype, st);
     case STV_OP_LOSS_COMBINE:
       // p0 parts, p1 table, p2 scale; q0 losses, q1 scores; cin = n_terms; f0 style_w, f1 content_w
-      // q2, q3 (optional): history ring and its device counter, n = ring capacity
+      // q2, q3 (optional): history ring and its device counter, n = ring capacity; p3 (optional, written): host-visible
+      // record count of a ring in host memory
       return stv_loss_combine_log(static_cast<const float*>(o.p0), static_cast<const int32_t*>(o.p1),
                                   static_cast<const float*>(o.p2), o.cin, o.f0, o.f1,
                                   static_cast<float*>(o.q0), static_cast<float*>(o.q1), static_cast<float*>(o.q2),
-                                  (int)o.n, static_cast<uint32_t*>(o.q3), st);
+                                  (int)o.n, static_cast<uint32_t*>(o.q3), static_cast<uint32_t*>(const_cast<void*>(o.p3)), st);
     case STV_OP_GRAM_MULTI:
       return stv_gram_multi(static_cast<const stv_gram_tap_t*>(o.p0), (int)o.n, o.dtype, st);
+    case STV_OP_LBFGS_STEP:
+      return stv_lbfgsc_step(static_cast<float*>(o.q0), static_cast<const float*>(o.p0), o.q1, o.q2, (size_t)o.n, o.cin, o.cout,
+                             o.f0, o.f1, o.f2, st);
     case STV_OP_MEMSET:
       if (hipMemsetAsync(o.q0, 0, (size_t)o.n, static_cast<hipStream_t>(st)) != hipSuccess)
         return STV_ERR_LAUNCH;

@@ -9,6 +9,8 @@ tensor and a flush is a single device-to-host copy.
 """
 from __future__ import annotations
 
+import os
+import time
 from dataclasses import dataclass
 
 import torch
@@ -53,17 +55,63 @@ class LossAccumulator:
         self._pending: tuple[int, torch.Tensor] | None = None
         self._last: LoggedLoss | None = None
         self._counter: torch.Tensor | None = None      # device-side record count, once a producer logs for us
+        # once a producer logs for us on a GPU: the ring moves to host memory the GPU writes into (ops.HostMailbox) and
+        # ``_seq`` is the record count the producer publishes behind each record - a flush then reads host memory as
+        # soon as the step's combine kernel has run, instead of copying from the device behind the whole step
+        self._box = None
+        self._seq: torch.Tensor | None = None
+        self._seq_np = None
+        self._pending_record: int | None = None        # the pending step's record number when the producer logged it
 
-    def device_log(self) -> tuple[torch.Tensor, torch.Tensor] | None:
-        """(ring [3, capacity] fp32, counter [1] int32) for a producer that appends each step's scores to the
-        history itself (``stv_loss_combine_log``: slot = counter % capacity, counter += 1) - the per-step copy
-        kernel then disappears from the step.  None when there is no fp32 device ring to share.  Records that
-        still arrive through :meth:`accumulate` without ``logged_by_producer`` keep the counter in step."""
-        if not self._ringed or self._ring is None or self._ring.dtype != torch.float32 or not self._ring.is_cuda:
+    def device_log(self) -> tuple[torch.Tensor, ...] | None:
+        """(ring [3, capacity] fp32, counter [1] int32[, seq [1] int32]) for a producer that appends each step's
+        scores to the history itself (``stv_loss_combine_log``: slot = counter % capacity, counter += 1) - the
+        per-step copy kernel then disappears from the step.  With ``seq`` the ring is HOST memory mapped into the
+        device (the producer publishes the record count there behind each record).  None when there is no fp32
+        ring to share.  Records that still arrive through :meth:`accumulate` without ``logged_by_producer`` keep
+        the counters in step."""
+        if not self._ringed or self._ring is None or self._ring.dtype != torch.float32:
+            return None
+        if self._box is None and not self._ring.is_cuda:
             return None
         if self._counter is None:
-            self._counter = torch.full((1,), self._records, dtype=torch.int32, device=self._ring.device)
+            self._counter = torch.full((1,), self._records, dtype=torch.int32, device=self._device)
+            self._adopt_host_ring()
+        if self._seq is not None:
+            return self._ring, self._counter, self._seq
         return self._ring, self._counter
+
+    def _adopt_host_ring(self) -> None:
+        """Move the ring into pinned, device-mapped host memory (STV_HOST_LOG=0: keep it on the device)."""
+        if os.environ.get("STV_HOST_LOG", "1") == "0" or self._ring is None:
+            return
+        from . import ops  # noqa: PLC0415
+        import numpy as np  # noqa: PLC0415
+        box = ops.HostMailbox(64 + 3 * self._capacity * 4)
+        ring = box.tensor(torch.float32, (3, self._capacity), offset=64)
+        if self._records:
+            ring.copy_(self._ring.cpu())
+        seq = box.tensor(torch.int32, (1,), offset=0)
+        seq[0] = self._records
+        self._box, self._ring, self._seq = box, ring, seq
+        self._seq_np = box.array(np.uint32, 1, 0)
+
+    def _wait_published(self, records: int) -> None:
+        """Until the producer has published ``records`` records (the combine kernel of that step has run)."""
+        if self._seq_np is None or int(self._seq_np[0]) >= records:
+            return
+        t0 = time.perf_counter()
+        spins = 0
+        while int(self._seq_np[0]) < records:
+            spins += 1
+            if spins > 2000:
+                time.sleep(2e-5)
+                if time.perf_counter() - t0 > 120.0:
+                    torch.cuda.synchronize(self._device)        # surfaces a device fault, if that is the reason
+                    if int(self._seq_np[0]) >= records:
+                        return
+                    msg = f"loss history: record {records} was never published by the device (seen {int(self._seq_np[0])})"
+                    raise RuntimeError(msg)
 
     @property
     def capacity(self) -> int:
@@ -90,6 +138,7 @@ class LossAccumulator:
             triple = torch.stack((style_loss.detach().reshape(()), content_loss.detach().reshape(()),
                                   total_loss.detach().reshape(())))
         self._pending = (step_idx, triple)
+        self._pending_record = None
         if self._ringed:
             if self._ring is None:
                 msg = "History buffers are uninitialized."
@@ -98,9 +147,15 @@ class LossAccumulator:
             if len(self._unchecked) > 2 * self._capacity:       # nobody drains (autograd path): stay bounded
                 del self._unchecked[:-self._capacity]
             if not (logged_by_producer and self._counter is not None):
-                self._ring[:, self._next] = triple.to(dtype=self._buffer_dtype, device=self._device)
+                if self._seq is not None:
+                    self._wait_published(self._records)          # (never overtake the producer's own records)
+                self._ring[:, self._next] = triple.to(dtype=self._buffer_dtype, device=self._ring.device)
                 if self._counter is not None:
                     self._counter += 1
+                if self._seq is not None:
+                    self._seq[0] = self._records + 1
+            elif self._seq is not None:
+                self._pending_record = self._records + 1
             self._next = (self._next + 1) % self._capacity
             self._count = min(self._count + 1, self._capacity)
             self._records += 1
@@ -134,6 +189,7 @@ class LossAccumulator:
         """Chronological bounded history as Python lists."""
         if not self._track or self._count == 0 or self._ring is None:
             return {k: [] for k in _KEYS}
+        self._wait_published(self._records)
         start = (self._next - self._count) % self._capacity
         if start + self._count <= self._capacity:
             window = self._ring[:, start:start + self._count]
@@ -150,6 +206,7 @@ class LossAccumulator:
         if not steps or self._ring is None:
             return []
         steps = steps[-min(self._count, self._capacity):]
+        self._wait_published(self._records)
         k = len(steps)
         start = (self._next - k) % self._capacity
         if start + k <= self._capacity:
@@ -163,7 +220,13 @@ class LossAccumulator:
         if self._pending is None:
             return None
         step, triple = self._pending
-        s, c, t = self._to_floats(triple)
+        if self._pending_record is not None and self._pending_record == self._records and self._ring is not None:
+            # the producer wrote this record into the host ring: wait for ITS combine kernel only
+            self._wait_published(self._pending_record)
+            slot = (self._next - 1) % self._capacity
+            s, c, t = (float(v) for v in self._ring[:, slot].tolist())
+        else:
+            s, c, t = self._to_floats(triple)
         self._last = LoggedLoss(step=step, style_loss=s, content_loss=c, total_loss=t)
         return self._last
 

@@ -399,6 +399,39 @@ def content_grad(F: torch.Tensor, target: torch.Tensor, dF: torch.Tensor, coef: 
                                     dtype_code(F.dtype), _stream()), "stv_content_grad")
 
 
+class HostMailbox:
+    """Pinned host memory the GPU writes while the CPU reads (``stv_host_mailbox_alloc``: mapped under the same
+    pointer on the device, fine-grained coherent, zeroed).  ``tensor`` / ``array`` are views; every view keeps this
+    object - and with it the allocation - alive."""
+
+    def __init__(self, nbytes: int) -> None:
+        out = ctypes.c_void_p()
+        _lib.check(_lib.load().stv_host_mailbox_alloc(int(nbytes), ctypes.byref(out)), "stv_host_mailbox_alloc")
+        self.ptr, self.nbytes = int(out.value), int(nbytes)
+        self._buf = (ctypes.c_char * self.nbytes).from_address(self.ptr)
+
+    def tensor(self, dtype: torch.dtype, shape: tuple, offset: int = 0) -> torch.Tensor:
+        count = 1
+        for d in shape:
+            count *= int(d)
+        t = torch.frombuffer(self._buf, dtype=dtype, count=count, offset=offset).view(*shape)
+        t._stv_owner = self          # (a program that baked this pointer into a graph keeps the tensor, hence the memory)
+        return t
+
+    def array(self, dtype, count: int, offset: int = 0):
+        import numpy as np  # noqa: PLC0415
+        a = np.frombuffer(self._buf, dtype=dtype, count=count, offset=offset)
+        return a
+
+    def __del__(self) -> None:
+        try:
+            if self.ptr:
+                _lib.load().stv_host_mailbox_free(self.ptr)
+                self.ptr = 0
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
 def loss_combine(parts: torch.Tensor, table: torch.Tensor, scale: torch.Tensor, style_w: float,
                  content_w: float, losses: torch.Tensor, scores: torch.Tensor) -> None:
     lib = _lib.load()

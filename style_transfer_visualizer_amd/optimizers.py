@@ -9,11 +9,46 @@ and branch stays on the GPU (``stv_lbfgs_step``), so ``step`` never syncs.
 from __future__ import annotations
 
 import os
+import threading
 from collections.abc import Callable
+from dataclasses import dataclass
 
 import torch
 
 from . import ops
+
+
+@dataclass
+class StepRequest:
+    """What ``HipLBFGS.step`` offers the closure: "if your evaluation is one command-buffer launch that ends
+    with the gradient of exactly this tensor, append my update to it" (``stv_op_t`` LBFGS_STEP, include/stv.h).
+    The model's fused path (``StyleContentModel.loss_and_grad``) takes it with :func:`claim_step`; closure and
+    update then replay as ONE hipGraph instead of a graph followed by four eager launches."""
+
+    x: torch.Tensor
+    state: torch.Tensor
+    work: torch.Tensor
+    history: int
+    lr: float
+    tol_grad: float
+    tol_change: float
+    taken: bool = False
+
+    def key(self) -> tuple:
+        return (self.state.data_ptr(), self.work.data_ptr(), self.history, self.lr, self.tol_grad, self.tol_change)
+
+
+_tls = threading.local()      # (style_transfer_batch runs images on several host threads)
+
+
+def claim_step(x: torch.Tensor) -> StepRequest | None:
+    """The pending request of the optimizer step this thread is inside of, if it is for ``x`` (same storage)
+    and nobody has taken it yet.  The taker MUST enqueue the update behind the gradient it computes."""
+    req = getattr(_tls, "pending", None)
+    if req is None or req.taken or req.x.data_ptr() != x.data_ptr() or req.x.numel() != x.numel():
+        return None
+    req.taken = True
+    return req
 
 
 def _single_param(params) -> torch.Tensor:
@@ -64,12 +99,25 @@ class HipLBFGS(torch.optim.Optimizer):
             raise ValueError(msg)
         self._dev_state, self._work = ops.lbfgs_alloc(p.numel(), history_size, p.device, compact=self._compact)
         self._steps = 0
+        # STV_FUSE_STEP=0: the update always as its own launches behind the closure
+        self._fuse = self._compact and shard_group is None and os.environ.get("STV_FUSE_STEP", "1") != "0"
 
     @torch.no_grad()
     def step(self, closure: Callable[[], torch.Tensor]) -> torch.Tensor:  # type: ignore[override]
-        with torch.enable_grad():
-            loss = closure()
         g = self.param_groups[0]
+        req = None
+        if self._fuse:
+            req = StepRequest(self._p, self._dev_state, self._work, int(g["history_size"]), float(g["lr"]),
+                              float(g["tolerance_grad"]), float(g["tolerance_change"]))
+            _tls.pending = req
+        try:
+            with torch.enable_grad():
+                loss = closure()
+        finally:
+            _tls.pending = None
+        if req is not None and req.taken:      # the closure's launch ended with this step's update
+            self._steps += 1
+            return loss
         grad = self._p.grad
         if grad is None:
             grad = torch.zeros_like(self._p)

@@ -210,8 +210,11 @@ def test_producer_logged_history_changes_nothing(bf16, monkeypatch):
     weights = case.weights()
     steps = 9
     results = {}
-    for mode in ("copy", "producer"):
+    for mode in ("copy", "producer", "producer_device_ring"):
         with monkeypatch.context() as mp:
+            # "producer": the ring is host memory the combine kernel writes into, a flush waits for that kernel only
+            # (no copy, no stream synchronisation); "producer_device_ring": STV_HOST_LOG=0, the ring stays on the device
+            mp.setenv("STV_HOST_LOG", "0" if mode == "producer_device_ring" else "1")
             mp.setattr(core_model, "initialize_vgg", lambda: core_model.build_vgg_features(weights, case.cfg).eval())
             mp.setattr(loss_accumulator, "DEFAULT_HISTORY_CAPACITY", 6)       # the ring wraps after six records
             mp.setattr(optimization, "DEFAULT_HISTORY_CAPACITY", 6)
@@ -236,11 +239,59 @@ def test_producer_logged_history_changes_nothing(bf16, monkeypatch):
                                                                precision="bf16" if bf16 else "fp32")
             runner = optimization.OptimizationRunner(model, x, cfg, optimizer=opt, progress_bar=_Bar())
             _, history, _ = runner.run()
-            results[mode] = (x.detach().clone(), history, handed)
-    assert results["producer"][2] == [True] * steps
+            results[mode] = (x.detach().clone(), history, handed, runner._loss_accumulator._box is not None)
+    assert [results[m][3] for m in ("copy", "producer", "producer_device_ring")] == [False, True, False]
+    assert results["producer"][2] == [True] * steps and results["producer_device_ring"][2] == [True] * steps
     assert torch.equal(results["copy"][0], results["producer"][0])
     assert results["copy"][1] == results["producer"][1]
+    assert torch.equal(results["copy"][0], results["producer_device_ring"][0])
+    assert results["copy"][1] == results["producer_device_ring"][1]
     assert len(results["producer"][1]["total_loss"]) == 6       # the last six of nine steps
+
+
+# ---------------------------------------------- optimizer update at the end of the closure's launch
+@pytest.mark.parametrize("bf16", [False, True])
+def test_update_fused_into_the_closure_launch_changes_nothing(bf16, monkeypatch):
+    """``HipLBFGS.step(closure)`` offers its update to the closure (optimizers.StepRequest); the model's fused path
+    appends it to its schedule (stv_op_t LBFGS_STEP), so a step is ONE replayed hipGraph.  Same kernels in the same
+    order: image, loss history and the optimizer's integer state are BIT-identical to STV_FUSE_STEP=0 (four eager
+    launches behind the graph), and every step of the fused run really took the offer."""
+    from style_transfer_visualizer_amd import optimizers
+    case = GoldenCase("mini_white_lbfgs")
+    weights = case.weights()
+    steps = 14
+    results = {}
+    for mode in ("0", "1"):
+        with monkeypatch.context() as mp:
+            mp.setenv("STV_FUSE_STEP", mode)
+            mp.setattr(core_model, "initialize_vgg", lambda: core_model.build_vgg_features(weights, case.cfg).eval())
+            taken = []
+            orig = optimizers.claim_step
+
+            def spy(x, orig=orig, taken=taken):
+                req = orig(x)
+                taken.append(req is not None)
+                return req
+            mp.setattr(optimizers, "claim_step", spy)
+            cfg = stv_config.StyleTransferConfig.model_validate({})
+            oc = cfg.optimization
+            oc.steps, oc.init_method, oc.seed = steps, "content", 0
+            oc.style_layers, oc.content_layers = list(case.meta["style_layers"]), list(case.meta["content_layers"])
+            cfg.video.create_video = False
+            content, style = case.images()
+            model, x, opt = core_model.prepare_model_and_input(content.to(DEV), style.to(DEV), DEV, oc,
+                                                               precision="bf16" if bf16 else "fp32")
+            assert isinstance(opt, optimizers.HipLBFGS)
+            runner = optimization.OptimizationRunner(model, x, cfg, optimizer=opt, progress_bar=_Bar())
+            _, history, _ = runner.run()
+            # a closure evaluated OUTSIDE optimizer.step must not find a request to take
+            model.loss_and_grad(x, oc.style_w, oc.content_w)
+            results[mode] = (x.detach().clone(), history, opt.device_state(), list(taken))
+    assert results["0"][3] == [False] * (steps + 1)
+    assert results["1"][3] == [True] * steps + [False]
+    assert torch.equal(results["0"][0], results["1"][0])
+    assert results["0"][1] == results["1"][1]
+    assert results["0"][2] == results["1"][2] and results["1"][2]["n_iter"] == steps
 
 
 # ------------------------------------------------------------------ input checks of the HIP model
