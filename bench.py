@@ -240,7 +240,10 @@ def run_gpu(args, rank: int, world: int, device: torch.device, size: int, steps:
     if rank == 0 and profile:
         # per-op device time of the fused step (HIP events on the launch stream), median of 5 passes
         eng = next(iter(model._engines.values()))
-        prog = next(p for k, p in eng._programs.items() if k[0] == "fused")
+        # the closure ALONE: evaluated outside optimizer.step, nothing rides at the end of its schedule (inside the
+        # runner the L-BFGS update is the schedule's last op, stv_op_t LBFGS_STEP; it is rated separately above)
+        model.loss_and_grad(x, oc.style_w, oc.content_w, live_scores=True)
+        prog = next(p for k, p in eng._programs.items() if k[0] == "fused" and k[-1] is None)
         OP = {n[3:]: getattr(_lib, n) for n in dir(_lib) if n.startswith("OP_")}
         side = torch.cuda.Stream(device=device)
 
