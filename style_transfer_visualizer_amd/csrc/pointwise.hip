@@ -627,7 +627,7 @@ extern "C" int stv_loss_combine_log(const float* parts, const int32_t* table, co
 extern "C" int stv_host_mailbox_alloc(size_t bytes, void** out) {
   if (!out || bytes == 0) return STV_ERR_ARG;
   void* p = nullptr;
-  if (hipHostMalloc(&p, bytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess || !p) {
+  if (hipHostMalloc(&p, bytes, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess || !p) {
     (void)hipGetLastError();
     return STV_ERR_ALLOC;
   }
