@@ -93,3 +93,85 @@ def test_audit_ring_keeps_scores_without_tracking_history():
     assert acc.drain_unchecked() == []
     assert not acc.tracks_history and not acc.history_truncated
     assert acc.export_history() == {"style_loss": [], "content_loss": [], "total_loss": []}
+
+
+class _FakeMailbox:
+    """Stands in for ops.HostMailbox on a machine without a GPU: plain host memory, same views."""
+
+    def __init__(self, nbytes: int) -> None:
+        import ctypes
+        self._buf = (ctypes.c_char * nbytes)()
+        self.ptr, self.nbytes = ctypes.addressof(self._buf), nbytes
+
+    def tensor(self, dtype, shape, offset=0):
+        count = 1
+        for d in shape:
+            count *= int(d)
+        return torch.frombuffer(self._buf, dtype=dtype, count=count, offset=offset).view(*shape)
+
+    def array(self, dtype, count, offset=0):
+        import numpy as np
+        return np.frombuffer(self._buf, dtype=dtype, count=count, offset=offset)
+
+
+def _host_ring_accumulator(monkeypatch, *, log_every=4, capacity=8, prior=0):
+    from style_transfer_visualizer_amd import ops
+    monkeypatch.setattr(ops, "HostMailbox", _FakeMailbox)
+    acc = LossAccumulator(log_every=log_every, history_capacity=capacity, track_history=True,
+                          device=torch.device("cpu"), dtype=torch.float32)
+    for k in range(prior):                       # records that arrived before any producer offered to log
+        acc.accumulate(k + 1, *(torch.tensor(float(10 * (k + 1) + j)) for j in range(3)))
+    acc._counter = torch.full((1,), acc._records, dtype=torch.int32)      # what device_log() does on a GPU
+    acc._adopt_host_ring()
+    assert acc._box is not None and acc.device_log() is not None and len(acc.device_log()) == 3
+    return acc
+
+
+def _produce(acc, record, values):
+    """What stv_loss_combine_log does: the record into its slot, then the count behind it."""
+    ring, counter, seq = acc.device_log()
+    slot = (record - 1) % ring.shape[1]
+    for j, v in enumerate(values):
+        ring[j, slot] = v
+    counter += 1
+    seq[0] = record
+
+
+def test_host_ring_flush_reads_what_the_producer_published(monkeypatch):
+    """The loss history ring in host memory written by the producer (stv_loss_combine_log with log_seq): a logging
+    point returns the producer's record without touching the live score tensors, history and audit read the same
+    ring, and records that arrived before the ring moved are kept."""
+    acc = _host_ring_accumulator(monkeypatch, log_every=4, capacity=8, prior=2)
+    live = torch.zeros(3)                        # stands for the engine's score buffer: already overwritten by a later step
+    for step in range(3, 9):
+        _produce(acc, step, (step + 0.25, step + 0.5, step + 0.75))
+        out = acc.accumulate(step, live[0], live[1], live[2], logged_by_producer=True)
+        if step % 4 == 0:
+            assert out is not None and (out.step, out.style_loss, out.content_loss, out.total_loss) == (
+                step, step + 0.25, step + 0.5, step + 0.75)
+        else:
+            assert out is None
+    hist = acc.export_history()
+    assert hist["style_loss"] == [10.0, 20.0, 3.25, 4.25, 5.25, 6.25, 7.25, 8.25]
+    assert [r[0] for r in acc.drain_unchecked()] == list(range(1, 9))
+
+
+def test_host_ring_flush_waits_for_the_producer(monkeypatch):
+    """The host may be ahead of the device: a logging point blocks until the record count says its step's combine
+    kernel has run (here a thread publishes 30 ms late), and a record that arrives WITHOUT the producer keeps ring,
+    device counter and published count in step."""
+    import threading
+    import time
+    acc = _host_ring_accumulator(monkeypatch, log_every=1, capacity=4)
+    t = threading.Timer(0.03, _produce, args=(acc, 1, (1.0, 2.0, 3.0)))
+    t0 = time.perf_counter()
+    t.start()
+    out = acc.accumulate(1, torch.tensor(9.0), torch.tensor(9.0), torch.tensor(9.0), logged_by_producer=True)
+    t.join()
+    assert time.perf_counter() - t0 >= 0.025
+    assert (out.style_loss, out.content_loss, out.total_loss) == (1.0, 2.0, 3.0)
+    out = acc.accumulate(2, torch.tensor(4.0), torch.tensor(5.0), torch.tensor(6.0))       # e.g. an autograd-path step
+    assert (out.style_loss, out.content_loss, out.total_loss) == (4.0, 5.0, 6.0)
+    ring, counter, seq = acc.device_log()
+    assert int(counter) == 2 and int(seq) == 2 and ring[:, 1].tolist() == [4.0, 5.0, 6.0]
+    assert acc.export_history()["total_loss"] == [3.0, 6.0]
