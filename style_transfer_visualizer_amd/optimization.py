@@ -35,7 +35,7 @@ from .constants import CSV_LOGGING_RECOMMENDED_STEPS
 from .logging_utils import logger
 from .loss_accumulator import DEFAULT_HISTORY_CAPACITY, LoggedLoss, LossAccumulator
 from .loss_logger import LossCSVLogger
-from .optimizers import HipAdam, HipLBFGS, make_lbfgs
+from .optimizers import HipAdam, HipLBFGS, make_lbfgs, single_evaluation
 from .type_defs import LossHistory
 
 
@@ -257,8 +257,10 @@ class OptimizationRunner:
                 "--log-loss to capture every step.", steps)
 
     # ------------------------------------------------------------------- closure
+    @single_evaluation
     def _closure(self) -> torch.Tensor:
-        """Closure handed to the optimizer; may run several times per step."""
+        """Closure handed to the optimizer; may run several times per step (each call evaluates the model once:
+        ``HipLBFGS`` may append its update to that evaluation's launch)."""
         self._closure_calls += 1
         if self._step_index >= self.total_steps:
             return self._final_loss_tensor()

@@ -41,6 +41,14 @@ class StepRequest:
 _tls = threading.local()      # (style_transfer_batch runs images on several host threads)
 
 
+def single_evaluation(closure):
+    """Mark a closure that evaluates the model exactly ONCE per call (and does nothing with the image afterwards):
+    only then may the update ride at the end of that evaluation's launch - a closure that evaluated twice would
+    compute its second gradient at the already updated image.  ``OptimizationRunner``'s closure is marked."""
+    closure._stv_single_eval = True
+    return closure
+
+
 def claim_step(x: torch.Tensor) -> StepRequest | None:
     """The pending request of the optimizer step this thread is inside of, if it is for ``x`` (same storage)
     and nobody has taken it yet.  The taker MUST enqueue the update behind the gradient it computes."""
@@ -106,7 +114,7 @@ class HipLBFGS(torch.optim.Optimizer):
     def step(self, closure: Callable[[], torch.Tensor]) -> torch.Tensor:  # type: ignore[override]
         g = self.param_groups[0]
         req = None
-        if self._fuse:
+        if self._fuse and getattr(closure, "_stv_single_eval", False):
             req = StepRequest(self._p, self._dev_state, self._work, int(g["history_size"]), float(g["lr"]),
                               float(g["tolerance_grad"]), float(g["tolerance_change"]))
             _tls.pending = req

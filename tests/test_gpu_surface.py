@@ -284,14 +284,19 @@ def test_update_fused_into_the_closure_launch_changes_nothing(bf16, monkeypatch)
             assert isinstance(opt, optimizers.HipLBFGS)
             runner = optimization.OptimizationRunner(model, x, cfg, optimizer=opt, progress_bar=_Bar())
             _, history, _ = runner.run()
-            # a closure evaluated OUTSIDE optimizer.step must not find a request to take
+            # a closure evaluated OUTSIDE optimizer.step must not find a request to take, and neither must a closure
+            # that does not promise to evaluate the model once per call (optimizers.single_evaluation)
             model.loss_and_grad(x, oc.style_w, oc.content_w)
-            results[mode] = (x.detach().clone(), history, opt.device_state(), list(taken))
-    assert results["0"][3] == [False] * (steps + 1)
-    assert results["1"][3] == [True] * steps + [False]
+            x_keep = x.detach().clone()
+            opt.step(lambda: model.loss_and_grad(x, oc.style_w, oc.content_w)[2])
+            with torch.no_grad():
+                x.copy_(x_keep)
+            results[mode] = (x_keep, history, opt.device_state(), list(taken))
+    assert results["0"][3] == [False] * (steps + 2)
+    assert results["1"][3] == [True] * steps + [False, False]
     assert torch.equal(results["0"][0], results["1"][0])
     assert results["0"][1] == results["1"][1]
-    assert results["0"][2] == results["1"][2] and results["1"][2]["n_iter"] == steps
+    assert results["0"][2] == results["1"][2] and results["1"][2]["n_iter"] == steps + 1
 
 
 # ------------------------------------------------------------------ input checks of the HIP model
