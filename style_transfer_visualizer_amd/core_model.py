@@ -10,7 +10,10 @@ CPU fallback: tensors must live on the GPU and the library must be built.
 """
 from __future__ import annotations
 
+import copy
+import hashlib
 import os
+import threading
 from pathlib import Path
 from urllib.parse import urlparse
 
@@ -165,6 +168,50 @@ def consume_classifier_init() -> None:
         nn.Linear(fan_in, fan_out)
 
 
+# initialize_vgg() of the torchvision-free branches costs 0.75 s per call (tools/setup_profile.py: 143 M uniform draws that
+# only exist to leave the CPU generator where torchvision's constructor would, 16 weight copies, the checkpoint load) - four
+# times the 0.17 s a 200-step run at 512^2 takes, once per image of a batch.  Both results are functions of their inputs: the
+# stack of (weight source), the generator state after of (generator state before).  So the process keeps the stack it built
+# (a CPU master, handed out as a deep copy) and, per generator state it has seen, the state construction left behind; a
+# second call from the same state (style_transfer reseeds per image) restores that state instead of drawing again.
+# STV_VGG_CACHE=0: always construct.
+_VGG_CACHE: dict = {}
+_VGG_CACHE_LOCK = threading.Lock()
+
+
+def clear_vgg_cache() -> None:
+    with _VGG_CACHE_LOCK:
+        _VGG_CACHE.clear()
+
+
+def _vgg_cache_get(key: tuple) -> nn.Module | None:
+    if os.environ.get("STV_VGG_CACHE", "1") == "0":
+        return None
+    digest = hashlib.sha1(torch.get_rng_state().numpy().tobytes()).digest()
+    with _VGG_CACHE_LOCK:
+        hit = _VGG_CACHE.get(key)
+        after = hit["rng"].get(digest) if hit is not None else None
+    if after is None:
+        return None
+    torch.set_rng_state(after.clone())
+    return copy.deepcopy(hit["master"])
+
+
+def _vgg_cache_put(key: tuple, before: torch.Tensor, vgg: nn.Module) -> None:
+    if os.environ.get("STV_VGG_CACHE", "1") == "0":
+        return
+    digest = hashlib.sha1(before.numpy().tobytes()).digest()
+    with _VGG_CACHE_LOCK:
+        hit = _VGG_CACHE.get(key)
+        if hit is None:
+            if len(_VGG_CACHE) >= 2:                      # (a stack is 80 MB of host memory)
+                _VGG_CACHE.pop(next(iter(_VGG_CACHE)))
+            hit = _VGG_CACHE[key] = {"master": copy.deepcopy(vgg), "rng": {}}
+        if len(hit["rng"]) >= 16:
+            hit["rng"].pop(next(iter(hit["rng"])))
+        hit["rng"][digest] = torch.get_rng_state()
+
+
 def initialize_vgg() -> nn.Module:
     """Frozen VGG19 feature stack (reference core_model.py:103-117).
 
@@ -172,10 +219,25 @@ def initialize_vgg() -> nn.Module:
     reference); the cached ``vgg19-dcbb9e9d.pth`` loaded into the
     torchvision-free topology; deterministic synthetic weights when
     ``STV_SYNTHETIC_WEIGHTS=<seed>`` is set (benchmarks / offline boxes).
+    The two torchvision-free branches are served from a per-process cache when weight source AND generator state
+    have been seen before (same stack, same generator state afterwards as constructing again).
     """
     cache_dir = Path(torch.hub.get_dir()) / "checkpoints"
     cache_path = cache_dir / Path(urlparse(VGG19_Weights.IMAGENET1K_V1.url).path).name
     synth = os.environ.get("STV_SYNTHETIC_WEIGHTS")
+    key = None
+    if synth is not None:
+        key = ("synthetic", synth)
+    elif vgg19 is None and cache_path.exists():
+        st = cache_path.stat()
+        key = ("checkpoint", str(cache_path), st.st_mtime_ns, st.st_size)
+    if key is not None:
+        cached = _vgg_cache_get(key)
+        if cached is not None:
+            logger.info("Using synthetic VGG19 weights (seed %s)", synth) if synth is not None else logger.info(
+                "Using cached VGG19 weights at %s", cache_path)
+            return cached
+    rng_before = torch.get_rng_state()
     if synth is not None:
         logger.info("Using synthetic VGG19 weights (seed %s)", synth)
         vgg = build_vgg_features(synthetic.synthetic_conv_weights(int(synth)))
@@ -200,6 +262,8 @@ def initialize_vgg() -> nn.Module:
     vgg = vgg.eval()
     for p in vgg.parameters():
         p.requires_grad_(False)  # noqa: FBT003
+    if key is not None:
+        _vgg_cache_put(key, rng_before, vgg)
     return vgg
 
 

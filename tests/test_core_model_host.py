@@ -235,6 +235,40 @@ def test_initialize_vgg_consumes_the_generator_like_torchvision_vgg19(monkeypatc
     assert torch.equal(got.detach(), want)
 
 
+def test_initialize_vgg_cache_returns_the_same_stack_and_generator_state(monkeypatch):
+    """The per-process cache of the torchvision-free branches: a second call from the same generator state returns
+    an independent copy of the same stack and leaves the generator exactly where constructing again would have -
+    the ``random`` start image drawn afterwards is the same; another generator state, or STV_VGG_CACHE=0, constructs."""
+    monkeypatch.setenv("STV_SYNTHETIC_WEIGHTS", "7")
+    core_model.clear_vgg_cache()
+    built = []
+    real_build = core_model.build_vgg_features
+    monkeypatch.setattr(core_model, "build_vgg_features", lambda *a, **k: (built.append(1), real_build(*a, **k))[1])
+    torch.manual_seed(99)
+    first = core_model.initialize_vgg()
+    want = torch.randn(3, 5)
+    torch.manual_seed(99)
+    second = core_model.initialize_vgg()
+    got = torch.randn(3, 5)
+    assert built == [1]                                           # the second call did not construct
+    assert torch.equal(got, want)
+    assert all(torch.equal(a, b) and a.data_ptr() != b.data_ptr() for a, b in zip(first.parameters(), second.parameters()))
+    assert not second.training and all(not p.requires_grad for p in second.parameters())
+    with torch.no_grad():
+        next(second.parameters()).zero_()                         # a caller's copy is its own
+    torch.manual_seed(99)
+    third = core_model.initialize_vgg()
+    assert torch.equal(next(third.parameters()), next(first.parameters()))
+    torch.manual_seed(100)                                        # a generator state not seen before: constructs
+    core_model.initialize_vgg()
+    assert built == [1, 1]
+    monkeypatch.setenv("STV_VGG_CACHE", "0")
+    torch.manual_seed(99)
+    core_model.initialize_vgg()
+    assert built == [1, 1, 1] and torch.equal(torch.randn(3, 5), want)
+    core_model.clear_vgg_cache()
+
+
 def test_initialize_vgg_goes_through_the_module_level_constructor(monkeypatch, tmp_path):
     """Reference tests/test_core_model.py:225-245: ``core_model.vgg19`` / ``core_model.VGG19_Weights`` are
     module-level names a caller can replace; the stack comes from ``vgg19(weights=IMAGENET1K_V1).features`` and is
